@@ -1,0 +1,181 @@
+/* srcfd.h -- C ABI of libsrcfd.so, the MI355X-native super-resolution engine.
+ *
+ * Drop-in boundary for ONE hot path of bitseal02/SR-for-CFD: the 10x10 ->
+ * 400x400 convolutional-autoencoder SR call.  The reference has no FFI layer;
+ * its boundary is the Python surface the solver scripts call, so every entry
+ * point below cites the reference call it replaces (paths relative to the
+ * reference checkout).  INTEGRATION.md shows the ctypes binding.
+ *
+ * Conventions: plain C, no torch / STL types.  Every function returns an int
+ * status (0 = SRCFD_OK, negative = error) unless noted, never throws, and
+ * leaves a thread-local message readable through srcfd_last_error().
+ * A handle is not thread-safe; distinct handles may be used from distinct
+ * threads.  Compute entry points fail with SRCFD_ENODEV when no HIP device is
+ * present -- there is no CPU fallback.
+ */
+#ifndef SRCFD_H
+#define SRCFD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SRCFD_OK 0
+#define SRCFD_ENOENT (-2)   /* file missing            -> Python FileNotFoundError (PyCFD_ML_accelerated.py:1080-1087) */
+#define SRCFD_EIO (-5)      /* unreadable / malformed  -> Python OSError           (PyCFD_ML_accelerated.py:835-837)   */
+#define SRCFD_ENOMEM (-12)
+#define SRCFD_ENODEV (-19)  /* no HIP device / extension cannot run */
+#define SRCFD_EINVAL (-22)
+#define SRCFD_EKEY (-126)   /* missing key             -> Python KeyError          (PyCFD_ML_accelerated.py:822-825)   */
+#define SRCFD_EHIP (-1000)  /* HIP runtime error, text in srcfd_last_error() */
+
+typedef enum {
+  SRCFD_F32 = 0, SRCFD_F64 = 1, SRCFD_I32 = 2, SRCFD_I64 = 3, SRCFD_U8 = 4, SRCFD_STR = 5,
+  SRCFD_BF16 = 16, SRCFD_F16 = 17
+} srcfd_dtype;
+
+/* Arithmetic the network is evaluated in. */
+typedef enum {
+  SRCFD_PREC_FP32 = 0,       /* f32 MFMA (v_mfma_f32_32x32x2_f32), exact f32 products: parity path     */
+  SRCFD_PREC_BF16 = 1,       /* bf16 operands, f32 accumulate, fused tail: throughput path             */
+  SRCFD_PREC_FP32_NAIVE = 2, /* one thread per output, f32 FMA chain: bring-up / cross-check           */
+  SRCFD_PREC_F16 = 3         /* f16 operands, f32 accumulate (BASELINE config 5)                        */
+} srcfd_precision;
+
+typedef enum {
+  SRCFD_LAYER_CONV2D = 1, SRCFD_LAYER_CONV2D_TRANSPOSE = 2, SRCFD_LAYER_DENSE = 3,
+  SRCFD_LAYER_FLATTEN = 4, SRCFD_LAYER_RESHAPE = 5
+} srcfd_layer_kind;
+
+typedef enum { SRCFD_ACT_LINEAR = 0, SRCFD_ACT_SWISH = 1, SRCFD_ACT_RELU = 2, SRCFD_ACT_SIGMOID = 3, SRCFD_ACT_TANH = 4 } srcfd_activation;
+
+/* One Keras layer (sr-ae-conv.ipynb:c162-169, c277-287).  Kernel layouts are
+ * Keras': Conv2D (kh,kw,Cin,Cout); Conv2DTranspose (kh,kw,Cout,Cin); Dense
+ * (in,out).  Pointers are host memory, copied at create. */
+typedef struct {
+  int kind;        /* srcfd_layer_kind */
+  int activation;  /* srcfd_activation */
+  int kh, kw, stride, same_padding; /* conv / conv-transpose */
+  int cin, cout;   /* channels (Dense: in/out features) */
+  int reshape[3];  /* RESHAPE target (h,w,c) */
+  const float* kernel;
+  const float* bias;
+} srcfd_layer;
+
+typedef struct srcfd_model srcfd_model;
+typedef struct srcfd_h5 srcfd_h5;
+typedef struct srcfd_h5w srcfd_h5w;
+
+const char* srcfd_last_error(void);
+const char* srcfd_version(void);
+/* Number of HIP devices (0 on a CPU-only box; never an error). */
+int srcfd_device_count(void);
+
+/* ---- model lifetime ------------------------------------------------------
+ * srcfd_model_load_h5 replaces the pair of
+ *   tf.keras.models.load_model(encoder_file, compile=False)
+ *   tf.keras.models.load_model(decoder_file, compile=False)
+ * + SuperResolutionAE(encoder_lr, decoder_hr)   (PyCFD_ML_accelerated.py:831-833,
+ * bfs_ml_accelerated.py:1069-1071): parses `model_config` and
+ * `model_weights/<layer>/<layer>/{kernel,bias}` from legacy Keras-H5 files and
+ * chains the sub-models.  Either path may be NULL to load one half.
+ * device < 0 builds a host-only handle (shape queries / weight access only). */
+int srcfd_model_load_h5(const char* encoder_h5, const char* decoder_h5, int device, srcfd_model** out);
+/* Same from in-memory layers (tests, training hand-off). in_shape = (h,w,c). */
+int srcfd_model_create(const srcfd_layer* layers, int n_layers, const int in_shape[3], int device, srcfd_model** out);
+void srcfd_model_destroy(srcfd_model* m);
+
+int srcfd_model_input_shape(const srcfd_model* m, int shape[3]);
+int srcfd_model_output_shape(const srcfd_model* m, int shape[3]);
+int srcfd_model_num_layers(const srcfd_model* m);
+/* Layer i: fills *layer with pointers into the handle's host copy of the weights. */
+int srcfd_model_get_layer(const srcfd_model* m, int i, srcfd_layer* layer, char* name, size_t name_len);
+/* Multiply-accumulates per sample (140 024 128 for encoder_10+decoder_400). */
+int64_t srcfd_model_macs_per_sample(const srcfd_model* m);
+int srcfd_model_set_precision(srcfd_model* m, int precision);
+int srcfd_model_get_precision(const srcfd_model* m);
+/* 1 when the bf16/f16 fused decoder_400 kernels apply to this layer graph. */
+int srcfd_model_has_fused_path(const srcfd_model* m);
+
+/* ---- forward -------------------------------------------------------------
+ * srcfd_predict replaces `inference_model.predict(x, verbose=0)`
+ * (PyCFD_ML_accelerated.py:858, bfs_ml_accelerated.py:1109, sr-ae-conv.ipynb:c349):
+ * x is float32 NHWC (n,h,w,c) C-contiguous host memory, y a caller-allocated
+ * float32 (n,oh,ow,oc) host buffer.  Blocks until y is complete.
+ *
+ * Optional fused pre/post-processing, per sample i (both may be NULL):
+ *   in_affine[2i..2i+1]  = (mean, std): x := (x - mean) / std in float32
+ *       (standardize_with_stats, PyCFD_ML_accelerated.py:665-668; std==0 -> 1e-8)
+ *   out_affine[2i..2i+1] = (mean, std): y := y * std + mean in float32, two
+ *       roundings like numpy (inverse_standardize, PyCFD_ML_accelerated.py:671-673)
+ * flags: SRCFD_FLAG_NAN_GUARD zero-fills NaN/Inf in y and counts them in
+ * *n_nonfinite (PyCFD_ML_accelerated.py:869-876). */
+#define SRCFD_FLAG_NAN_GUARD 1
+int srcfd_predict(srcfd_model* m, const float* x, int n, const float* in_affine, const float* out_affine,
+                  float* y, int flags, int64_t* n_nonfinite);
+
+/* Device-resident variant for the batched path: x_dev float32 (n,h,w,c),
+ * affines float32 device arrays or NULL, y_dev of dtype out_dtype (SRCFD_F32,
+ * SRCFD_BF16 or SRCFD_F16), nonfinite_dev an optional device int64 counter
+ * that is ADDED to.  Enqueues on hip_stream (a hipStream_t, NULL = default
+ * stream) and returns without synchronising. */
+int srcfd_predict_device(srcfd_model* m, const void* x_dev, int n, const float* in_affine_dev,
+                         const float* out_affine_dev, void* y_dev, int out_dtype, int flags,
+                         int64_t* nonfinite_dev, void* hip_stream);
+/* Largest n one srcfd_predict_device call processes without internal chunking
+ * at the current precision, and the workspace bytes it holds for that. */
+int srcfd_model_workspace(srcfd_model* m, int n, size_t* bytes);
+
+/* Per-kernel timing of the last srcfd_predict_device call made with profiling
+ * enabled: HIP events on the launch stream around every kernel.  names is a
+ * '\n'-joined list; ms has one entry per name. */
+int srcfd_model_set_profiling(srcfd_model* m, int enable);
+int srcfd_model_get_profile(srcfd_model* m, char* names, size_t names_len, float* ms, int* count, int max_count);
+
+/* ---- stats file ----------------------------------------------------------
+ * `key value` lines, '#' comments (PyCFD_ML_accelerated.py:787-797).  Looks up
+ * mean{lr}_{c}, std{lr}_{c}, mean{hr}_{c}, std{hr}_{c} for c in u,v,p
+ * (PyCFD_ML_accelerated.py:800-809) into out[12] = lr(u,v,p)x(mean,std) then
+ * hr(u,v,p)x(mean,std).  SRCFD_ENOENT / SRCFD_EKEY as the reference raises. */
+int srcfd_stats_load(const char* path, int lr_dim, int hr_dim, double out[12]);
+/* Writer of the same format (sr-ae-conv.ipynb:c589-603). */
+int srcfd_stats_save(const char* path, int lr_dim, int hr_dim, const double in[12]);
+
+/* ---- HDF5 subset (legacy Keras-H5, solver field dumps) -------------------
+ * Replaces h5py for this path: reads what `load_model` reads
+ * (PyCFD_ML_accelerated.py:831-832) and the coarse-field files the solvers
+ * write (PyCFD_ML_accelerated.py:517-544); writes the layout
+ * `encoder.save(...h5)` produces (sr-ae-conv.ipynb:c584-586). */
+int srcfd_h5_open(const char* path, srcfd_h5** out);
+void srcfd_h5_close(srcfd_h5* f);
+/* '\n'-joined child names of a group; *needed = bytes incl. terminator. */
+int srcfd_h5_list(srcfd_h5* f, const char* group, char* buf, size_t buf_len, size_t* needed);
+/* kind: 0 absent, 1 group, 2 dataset. */
+int srcfd_h5_kind(srcfd_h5* f, const char* path);
+int srcfd_h5_dataset_info(srcfd_h5* f, const char* path, int* dtype, int* rank, uint64_t dims[8]);
+int srcfd_h5_read(srcfd_h5* f, const char* path, void* dst, size_t dst_bytes, int as_dtype);
+/* String attribute ('\n'-joined when an array); numeric attribute as doubles. */
+int srcfd_h5_attr_string(srcfd_h5* f, const char* obj, const char* name, char* buf, size_t buf_len, size_t* needed);
+int srcfd_h5_attr_numeric(srcfd_h5* f, const char* obj, const char* name, double* out, int max_count, int* count);
+int srcfd_h5_attr_names(srcfd_h5* f, const char* obj, char* buf, size_t buf_len, size_t* needed);
+
+int srcfd_h5w_create(srcfd_h5w** out);
+void srcfd_h5w_free(srcfd_h5w* w);
+int srcfd_h5w_group(srcfd_h5w* w, const char* path);
+int srcfd_h5w_dataset(srcfd_h5w* w, const char* path, int dtype, int rank, const uint64_t* dims, const void* data);
+/* n_strings == 0 writes a scalar string attribute from strings[0]. */
+int srcfd_h5w_attr_strings(srcfd_h5w* w, const char* obj, const char* name, const char* const* strings,
+                           int n_strings, int is_scalar, int utf8);
+int srcfd_h5w_attr_numeric(srcfd_h5w* w, const char* obj, const char* name, int dtype, const void* value, int count, int is_scalar);
+int srcfd_h5w_save(srcfd_h5w* w, const char* path);
+/* Saves the handle's weights as legacy Keras-H5 sub-model files
+ * (sr-ae-conv.ipynb:c584-585); split_at = index of the first decoder layer. */
+int srcfd_model_save_h5(const srcfd_model* m, const char* encoder_h5, const char* decoder_h5);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SRCFD_H */

@@ -1,0 +1,127 @@
+"""ctypes binding of libsrcfd.so (C ABI in include/srcfd.h).
+
+The library is the product: if it is missing or cannot be loaded this module
+raises -- there is no Python/CPU fallback for the compute path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsrcfd.so")
+
+OK, ENOENT, EIO, ENOMEM, ENODEV, EINVAL, EKEY, EHIP = 0, -2, -5, -12, -19, -22, -126, -1000
+
+F32, F64, I32, I64, U8, STR, BF16, F16 = 0, 1, 2, 3, 4, 5, 16, 17
+PREC_FP32, PREC_BF16, PREC_FP32_NAIVE, PREC_F16 = 0, 1, 2, 3
+LAYER_CONV2D, LAYER_CONV2D_TRANSPOSE, LAYER_DENSE, LAYER_FLATTEN, LAYER_RESHAPE = 1, 2, 3, 4, 5
+ACT_LINEAR, ACT_SWISH, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
+FLAG_NAN_GUARD = 1
+
+
+class SrcfdError(RuntimeError):
+    """Any libsrcfd failure that has no closer built-in exception type."""
+
+
+class NoDeviceError(SrcfdError):
+    """No HIP device (SRCFD_ENODEV): the extension cannot compute here."""
+
+
+class Layer(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int), ("activation", C.c_int),
+        ("kh", C.c_int), ("kw", C.c_int), ("stride", C.c_int), ("same_padding", C.c_int),
+        ("cin", C.c_int), ("cout", C.c_int),
+        ("reshape", C.c_int * 3),
+        ("kernel", C.POINTER(C.c_float)), ("bias", C.POINTER(C.c_float)),
+    ]
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C sr-for-cfd_amd/csrc` (hipcc, --offload-arch=gfx950). There is no CPU fallback.")
+    return C.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+_p = C.c_void_p
+_sz = C.c_size_t
+_protos = {
+    "srcfd_last_error": (C.c_char_p, []),
+    "srcfd_version": (C.c_char_p, []),
+    "srcfd_device_count": (C.c_int, []),
+    "srcfd_model_load_h5": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(_p)]),
+    "srcfd_model_create": (C.c_int, [C.POINTER(Layer), C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(_p)]),
+    "srcfd_model_destroy": (None, [_p]),
+    "srcfd_model_input_shape": (C.c_int, [_p, C.POINTER(C.c_int)]),
+    "srcfd_model_output_shape": (C.c_int, [_p, C.POINTER(C.c_int)]),
+    "srcfd_model_num_layers": (C.c_int, [_p]),
+    "srcfd_model_get_layer": (C.c_int, [_p, C.c_int, C.POINTER(Layer), C.c_char_p, _sz]),
+    "srcfd_model_macs_per_sample": (C.c_int64, [_p]),
+    "srcfd_model_set_precision": (C.c_int, [_p, C.c_int]),
+    "srcfd_model_get_precision": (C.c_int, [_p]),
+    "srcfd_model_has_fused_path": (C.c_int, [_p]),
+    "srcfd_predict": (C.c_int, [_p, _p, C.c_int, _p, _p, _p, C.c_int, C.POINTER(C.c_int64)]),
+    "srcfd_predict_device": (C.c_int, [_p, _p, C.c_int, _p, _p, _p, C.c_int, C.c_int, _p, _p]),
+    "srcfd_model_workspace": (C.c_int, [_p, C.c_int, C.POINTER(_sz)]),
+    "srcfd_model_set_profiling": (C.c_int, [_p, C.c_int]),
+    "srcfd_model_get_profile": (C.c_int, [_p, C.c_char_p, _sz, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]),
+    "srcfd_model_save_h5": (C.c_int, [_p, C.c_char_p, C.c_char_p]),
+    "srcfd_stats_load": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "srcfd_stats_save": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
+    "srcfd_h5_open": (C.c_int, [C.c_char_p, C.POINTER(_p)]),
+    "srcfd_h5_close": (None, [_p]),
+    "srcfd_h5_list": (C.c_int, [_p, C.c_char_p, C.c_char_p, _sz, C.POINTER(_sz)]),
+    "srcfd_h5_kind": (C.c_int, [_p, C.c_char_p]),
+    "srcfd_h5_dataset_info": (C.c_int, [_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_uint64)]),
+    "srcfd_h5_read": (C.c_int, [_p, C.c_char_p, _p, _sz, C.c_int]),
+    "srcfd_h5_attr_string": (C.c_int, [_p, C.c_char_p, C.c_char_p, C.c_char_p, _sz, C.POINTER(_sz)]),
+    "srcfd_h5_attr_numeric": (C.c_int, [_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_double), C.c_int, C.POINTER(C.c_int)]),
+    "srcfd_h5_attr_names": (C.c_int, [_p, C.c_char_p, C.c_char_p, _sz, C.POINTER(_sz)]),
+    "srcfd_h5w_create": (C.c_int, [C.POINTER(_p)]),
+    "srcfd_h5w_free": (None, [_p]),
+    "srcfd_h5w_group": (C.c_int, [_p, C.c_char_p]),
+    "srcfd_h5w_dataset": (C.c_int, [_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_uint64), _p]),
+    "srcfd_h5w_attr_strings": (C.c_int, [_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_char_p), C.c_int, C.c_int, C.c_int]),
+    "srcfd_h5w_attr_numeric": (C.c_int, [_p, C.c_char_p, C.c_char_p, C.c_int, _p, C.c_int, C.c_int]),
+    "srcfd_h5w_save": (C.c_int, [_p, C.c_char_p]),
+}
+for _name, (_res, _args) in _protos.items():
+    _fn = getattr(lib, _name)  # AttributeError here = ABI drift, fail loudly
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+EXPORTED = tuple(_protos)
+
+
+def last_error() -> str:
+    return (lib.srcfd_last_error() or b"").decode("utf-8", "replace")
+
+
+def check(rc: int) -> int:
+    """Map a status code to the exception the reference's Python would raise
+    (SURVEY.md 8b 'errors')."""
+    if rc >= 0:
+        return rc
+    msg = last_error()
+    if rc == ENOENT:
+        raise FileNotFoundError(msg)
+    if rc == EIO:
+        raise OSError(msg)
+    if rc == EKEY:
+        raise KeyError(msg)
+    if rc == EINVAL:
+        raise ValueError(msg)
+    if rc == ENOMEM:
+        raise MemoryError(msg)
+    if rc == ENODEV:
+        raise NoDeviceError(msg)
+    raise SrcfdError(f"libsrcfd error {rc}: {msg}")
+
+
+def enc(path) -> bytes:
+    return os.fsencode(path)

@@ -1,0 +1,78 @@
+// Internal engine types (not part of the C ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+#include "model.h"
+
+namespace srcfd {
+
+extern thread_local std::string g_last_error;
+void set_error(const std::string& m);
+
+struct Op {
+  GemmDesc d;           // M filled per call (rows per image * batch)
+  size_t w_off = 0;     // into the packed float buffer: B[K][Npad]
+  size_t b_off = 0;     // bias[Npad]
+  int layer = 0;        // index into ModelDesc::layers
+  std::string name;
+};
+
+void build_plan(const ModelDesc& desc, std::vector<Op>& ops, std::vector<float>& pack);
+
+struct ProfEvent {
+  hipEvent_t a, b;
+  std::string name;
+};
+
+struct FusedState;  // bf16/f16 path (fused_bf16.hip)
+
+struct Model {
+  ModelDesc desc;
+  int device = -1;
+  int precision = SRCFD_PREC_FP32;
+  bool has_fused = false;
+
+  std::vector<Op> ops;
+  std::vector<float> pack;  // host copy of packed weights
+  float* d_pack = nullptr;
+
+  float* buf[2] = {nullptr, nullptr};
+  int ws_chunk = 0;
+  float* d_x_stage = nullptr;
+  float* d_y_stage = nullptr;
+  float* d_aff = nullptr;
+  int stage_chunk = 0;
+  unsigned long long* d_nonfinite = nullptr;
+
+  bool profiling = false;
+  std::vector<ProfEvent> prof_events;
+  size_t prof_used = 0;
+
+  FusedState* fused = nullptr;
+
+  ~Model();
+  int init_device();
+  void free_workspace();
+  size_t max_act_elems() const;
+  int chunk_cap() const;
+  int ensure_workspace(int n);
+  int launch(const char* name, hipStream_t s, const std::function<hipError_t()>& fn);
+  int forward_generic(const float* x_dev, int n, const float* aff_in, const float* aff_out, void* y_dev, int out_dtype, int flags,
+                      unsigned long long* nonfinite, hipStream_t s);
+  int predict_device(const void* x_dev, int n, const float* aff_in, const float* aff_out, void* y_dev, int out_dtype, int flags,
+                     unsigned long long* nonfinite, hipStream_t s);
+  int predict_host(const float* x, int n, const float* aff_in, const float* aff_out, float* y, int flags, int64_t* n_nonfinite);
+};
+
+// bf16 / f16 fused path for the encoder_10 + decoder_400 graph.
+int fused_init(Model& m);
+void fused_free(Model& m);
+int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, const float* aff_out, void* y_dev, int out_dtype,
+                  int flags, unsigned long long* nonfinite, hipStream_t s);
+
+}  // namespace srcfd

@@ -1,0 +1,496 @@
+// srcfd engine: builds the kernel plan for a layer graph, owns device weights
+// and workspaces, and exports the model part of the C ABI (include/srcfd.h).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "engine.h"
+
+namespace srcfd {
+
+thread_local std::string g_last_error;
+void set_error(const std::string& m) { g_last_error = m; }
+
+#define HIPCHECK(expr)                                                                              \
+  do {                                                                                              \
+    hipError_t _e = (expr);                                                                         \
+    if (_e != hipSuccess) {                                                                         \
+      set_error(std::string(#expr) + " failed: " + hipGetErrorString(_e));                          \
+      return SRCFD_EHIP;                                                                            \
+    }                                                                                               \
+  } while (0)
+
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// ---------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------
+static void pack_B(std::vector<float>& pack, Op& op, const std::vector<float>& Bmat /*[K][N]*/, const std::vector<float>& bias_n) {
+  const GemmDesc& d = op.d;
+  while (pack.size() % 64) pack.push_back(0.f);  // 256-byte aligned sub-buffers
+  op.w_off = pack.size();
+  pack.resize(pack.size() + (size_t)std::max(d.K, 1) * d.Npad, 0.f);
+  for (int k = 0; k < d.K; ++k)
+    std::memcpy(&pack[op.w_off + (size_t)k * d.Npad], &Bmat[(size_t)k * d.N], sizeof(float) * d.N);
+  while (pack.size() % 64) pack.push_back(0.f);
+  op.b_off = pack.size();
+  pack.resize(pack.size() + d.Npad, 0.f);
+  std::memcpy(&pack[op.b_off], bias_n.data(), sizeof(float) * d.N);
+}
+
+void build_plan(const ModelDesc& desc, std::vector<Op>& ops, std::vector<float>& pack) {
+  ops.clear();
+  pack.clear();
+  for (size_t li = 0; li < desc.layers.size(); ++li) {
+    const Layer& L = desc.layers[li];
+    if (L.kind == SRCFD_LAYER_FLATTEN || L.kind == SRCFD_LAYER_RESHAPE) continue;  // views of NHWC buffers
+    const int IH = L.in_shape[0], IW = L.in_shape[1], OH = L.out_shape[0], OW = L.out_shape[1];
+    GemmDesc d{};
+    d.act = L.act;
+    d.OH = OH; d.OW = OW; d.OC = L.cout; d.CO = L.cout;
+    d.nphx = 1; d.os = 1;
+    d.IH = IH; d.IW = IW; d.CI = L.cin;
+    if (L.kind == SRCFD_LAYER_DENSE) {
+      d.IH = d.IW = 1; d.CI = L.cin; d.OH = d.OW = 1;
+      d.MH = d.MW = 1; d.TY = d.TX = 1;
+      d.K = L.cin; d.N = L.cout; d.Npad = round_up(d.N, 32);
+      Op op; op.d = d; op.layer = (int)li; op.name = L.name;
+      pack_B(pack, op, L.kernel, L.bias);
+      ops.push_back(op);
+    } else if (L.kind == SRCFD_LAYER_CONV2D) {
+      int pt = 0, pl = 0;
+      if (L.same) {
+        int th = std::max((OH - 1) * L.stride + L.kh - IH, 0), tw = std::max((OW - 1) * L.stride + L.kw - IW, 0);
+        pt = th / 2; pl = tw / 2;  // TF SAME: the extra pixel goes after
+      }
+      d.MH = OH; d.MW = OW; d.TY = L.kh; d.TX = L.kw;
+      d.ay = d.ax = L.stride; d.by = d.bx = 1; d.cy = -pt; d.cx = -pl;
+      d.K = L.kh * L.kw * L.cin; d.N = L.cout; d.Npad = round_up(d.N, 32);
+      Op op; op.d = d; op.layer = (int)li; op.name = L.name;
+      pack_B(pack, op, L.kernel, L.bias);  // (kh,kw,Cin,Cout) is already [K][N]
+      ops.push_back(op);
+    } else {  // Conv2DTranspose, VALID, kernel (kh,kw,Cout,Cin)
+      const int s = L.stride;
+      auto W = [&](int a, int b, int co, int ci) { return L.kernel[(((size_t)a * L.kw + b) * L.cout + co) * L.cin + ci]; };
+      if (L.kh == s && L.kw == s) {
+        d.MH = IH; d.MW = IW; d.TY = d.TX = 1;
+        d.ay = d.ax = 1; d.by = d.bx = 0; d.cy = d.cx = 0;
+        d.K = L.cin; d.N = s * s * L.cout; d.Npad = round_up(d.N, 32);
+        d.nphx = s; d.os = s;
+        std::vector<float> B((size_t)d.K * d.N), bn(d.N);
+        for (int ci = 0; ci < L.cin; ++ci)
+          for (int py = 0; py < s; ++py)
+            for (int px = 0; px < s; ++px)
+              for (int co = 0; co < L.cout; ++co) B[(size_t)ci * d.N + (py * s + px) * L.cout + co] = W(py, px, co, ci);
+        for (int n = 0; n < d.N; ++n) bn[n] = L.bias[n % L.cout];
+        Op op; op.d = d; op.layer = (int)li; op.name = L.name;
+        pack_B(pack, op, B, bn);
+        ops.push_back(op);
+      } else {
+        for (int py = 0; py < s; ++py)
+          for (int px = 0; px < s; ++px) {
+            GemmDesc p = d;
+            p.TY = py < L.kh ? (L.kh - py + s - 1) / s : 0;
+            p.TX = px < L.kw ? (L.kw - px + s - 1) / s : 0;
+            p.MH = py < OH ? (OH - py + s - 1) / s : 0;
+            p.MW = px < OW ? (OW - px + s - 1) / s : 0;
+            if (p.MH == 0 || p.MW == 0) continue;
+            p.ay = p.ax = 1; p.by = p.bx = -1; p.cy = p.cx = 0;
+            p.K = p.TY * p.TX * L.cin; p.N = L.cout; p.Npad = round_up(p.N, 32);
+            p.os = s; p.oy0 = py; p.ox0 = px;
+            std::vector<float> B((size_t)std::max(p.K, 1) * p.N, 0.f);
+            for (int ty = 0; ty < p.TY; ++ty)
+              for (int tx = 0; tx < p.TX; ++tx)
+                for (int ci = 0; ci < L.cin; ++ci)
+                  for (int co = 0; co < L.cout; ++co)
+                    B[((size_t)(ty * p.TX + tx) * L.cin + ci) * p.N + co] = W(py + s * ty, px + s * tx, co, ci);
+            Op op; op.d = p; op.layer = (int)li;
+            op.name = L.name + ".ph" + std::to_string(py) + std::to_string(px);
+            pack_B(pack, op, B, L.bias);
+            ops.push_back(op);
+          }
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// model
+// ---------------------------------------------------------------------------
+Model::~Model() {
+  if (device >= 0) {
+    (void)hipSetDevice(device);
+    free_workspace();
+    if (d_pack) (void)hipFree(d_pack);
+    fused_free(*this);
+    for (auto& e : prof_events) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  }
+}
+
+void Model::free_workspace() {
+  for (int i = 0; i < 2; ++i) if (buf[i]) { (void)hipFree(buf[i]); buf[i] = nullptr; }
+  for (void* p : {(void*)d_x_stage, (void*)d_y_stage, (void*)d_aff, (void*)d_nonfinite}) if (p) (void)hipFree(p);
+  d_x_stage = d_y_stage = nullptr; d_aff = nullptr; d_nonfinite = nullptr;
+  ws_chunk = 0; stage_chunk = 0;
+}
+
+int Model::init_device() {
+  if (device < 0) return SRCFD_OK;
+  int cnt = 0;
+  if (hipGetDeviceCount(&cnt) != hipSuccess || cnt <= 0) {
+    (void)hipGetLastError();
+    set_error("no HIP device available (libsrcfd has no CPU fallback)");
+    return SRCFD_ENODEV;
+  }
+  if (device >= cnt) { set_error("device index out of range"); return SRCFD_EINVAL; }
+  HIPCHECK(hipSetDevice(device));
+  HIPCHECK(hipMalloc(&d_pack, pack.size() * sizeof(float)));
+  HIPCHECK(hipMemcpy(d_pack, pack.data(), pack.size() * sizeof(float), hipMemcpyHostToDevice));
+  return SRCFD_OK;
+}
+
+size_t Model::max_act_elems() const {
+  size_t m = (size_t)desc.in_shape[0] * desc.in_shape[1] * desc.in_shape[2];
+  for (auto& L : desc.layers) m = std::max(m, (size_t)L.out_shape[0] * L.out_shape[1] * L.out_shape[2]);
+  return m;
+}
+
+int Model::chunk_cap() const {
+  size_t per = 2 * max_act_elems() * sizeof(float);
+  size_t cap = ((size_t)3 << 30) / std::max<size_t>(per, 1);
+  return (int)std::max<size_t>(1, std::min<size_t>(cap, 256));
+}
+
+int Model::ensure_workspace(int n) {
+  int chunk = std::min(n, chunk_cap());
+  if (chunk <= ws_chunk) return SRCFD_OK;
+  for (int i = 0; i < 2; ++i) if (buf[i]) { HIPCHECK(hipFree(buf[i])); buf[i] = nullptr; }
+  ws_chunk = 0;
+  size_t bytes = (size_t)chunk * max_act_elems() * sizeof(float);
+  for (int i = 0; i < 2; ++i) HIPCHECK(hipMalloc(&buf[i], bytes));
+  ws_chunk = chunk;
+  return SRCFD_OK;
+}
+
+int Model::launch(const char* name, hipStream_t s, const std::function<hipError_t()>& fn) {
+  ProfEvent* pe = nullptr;
+  if (profiling) {
+    if (prof_used == prof_events.size()) {
+      ProfEvent e;
+      HIPCHECK(hipEventCreate(&e.a));
+      HIPCHECK(hipEventCreate(&e.b));
+      prof_events.push_back(e);
+    }
+    pe = &prof_events[prof_used++];
+    pe->name = name;
+    HIPCHECK(hipEventRecord(pe->a, s));
+  }
+  hipError_t e = fn();
+  if (e != hipSuccess) { set_error(std::string("launch of ") + name + " failed: " + hipGetErrorString(e)); return SRCFD_EHIP; }
+  if (pe) HIPCHECK(hipEventRecord(pe->b, s));
+  return SRCFD_OK;
+}
+
+// Generic layer-by-layer f32 forward of one chunk (<= ws_chunk samples).
+int Model::forward_generic(const float* x_dev, int n, const float* aff_in, const float* aff_out, void* y_dev, int out_dtype,
+                           int flags, unsigned long long* nonfinite, hipStream_t s) {
+  const int in_elems = desc.in_shape[0] * desc.in_shape[1] * desc.in_shape[2];
+  const int* os = desc.out_shape();
+  const int out_elems = os[0] * os[1] * os[2];
+  const bool naive = precision == SRCFD_PREC_FP32_NAIVE;
+  int cur = 0;
+  int rc = launch("standardize", s, [&] { return launch_standardize(x_dev, buf[0], aff_in, in_elems, (int64_t)n * in_elems, s); });
+  if (rc) return rc;
+  int prev_layer = -1;
+  for (size_t i = 0; i < ops.size(); ++i) {
+    const Op& op = ops[i];
+    if (op.layer != prev_layer && prev_layer >= 0) cur ^= 1;
+    prev_layer = op.layer;
+    GemmDesc d = op.d;
+    d.M = n * d.MH * d.MW;
+    const float* X = buf[cur];
+    float* Y = buf[cur ^ 1];
+    const float* B = d_pack + op.w_off;
+    const float* bias = d_pack + op.b_off;
+    rc = launch(op.name.c_str(), s, [&] { return naive ? launch_gemm_naive(d, X, B, bias, Y, s) : launch_gemm_mfma(d, X, B, bias, Y, s); });
+    if (rc) return rc;
+  }
+  cur ^= 1;
+  return launch("finalize", s, [&] {
+    return launch_finalize(buf[cur], y_dev, out_dtype, aff_out, out_elems, (int64_t)n * out_elems, flags & SRCFD_FLAG_NAN_GUARD, nonfinite, s);
+  });
+}
+
+int Model::predict_device(const void* x_dev, int n, const float* aff_in, const float* aff_out, void* y_dev, int out_dtype, int flags,
+                          unsigned long long* nonfinite, hipStream_t s) {
+  if (device < 0) { set_error("host-only handle: no device was requested at create"); return SRCFD_ENODEV; }
+  if (n < 0) { set_error("negative batch"); return SRCFD_EINVAL; }
+  if (out_dtype != SRCFD_F32 && out_dtype != SRCFD_BF16 && out_dtype != SRCFD_F16) { set_error("unsupported output dtype"); return SRCFD_EINVAL; }
+  if (n == 0) return SRCFD_OK;
+  HIPCHECK(hipSetDevice(device));
+  prof_used = 0;
+  const bool fused = (precision == SRCFD_PREC_BF16 || precision == SRCFD_PREC_F16);
+  if (fused) {
+    if (!has_fused) { set_error("bf16/f16 precision needs the encoder_10+decoder_400 layer graph; use SRCFD_PREC_FP32 for other graphs"); return SRCFD_EINVAL; }
+    return fused_forward(*this, (const float*)x_dev, n, aff_in, aff_out, y_dev, out_dtype, flags, nonfinite, s);
+  }
+  int rc = ensure_workspace(n);
+  if (rc) return rc;
+  const int in_elems = desc.in_shape[0] * desc.in_shape[1] * desc.in_shape[2];
+  const int* os = desc.out_shape();
+  const size_t out_elems = (size_t)os[0] * os[1] * os[2];
+  const size_t osz = out_dtype == SRCFD_F32 ? 4 : 2;
+  for (int i = 0; i < n; i += ws_chunk) {
+    int c = std::min(ws_chunk, n - i);
+    rc = forward_generic((const float*)x_dev + (size_t)i * in_elems, c, aff_in ? aff_in + 2 * (size_t)i : nullptr,
+                         aff_out ? aff_out + 2 * (size_t)i : nullptr, (char*)y_dev + (size_t)i * out_elems * osz, out_dtype, flags,
+                         nonfinite, s);
+    if (rc) return rc;
+  }
+  return SRCFD_OK;
+}
+
+int Model::predict_host(const float* x, int n, const float* aff_in, const float* aff_out, float* y, int flags, int64_t* n_nonfinite) {
+  if (device < 0) { set_error("host-only handle: no device was requested at create"); return SRCFD_ENODEV; }
+  if (n < 0 || (n > 0 && (!x || !y))) { set_error("bad arguments"); return SRCFD_EINVAL; }
+  if (n_nonfinite) *n_nonfinite = 0;
+  if (n == 0) return SRCFD_OK;
+  HIPCHECK(hipSetDevice(device));
+  const size_t in_elems = (size_t)desc.in_shape[0] * desc.in_shape[1] * desc.in_shape[2];
+  const int* os = desc.out_shape();
+  const size_t out_elems = (size_t)os[0] * os[1] * os[2];
+  int chunk = std::min(n, 256);
+  if (chunk > stage_chunk) {
+    for (void* p : {(void*)d_x_stage, (void*)d_y_stage, (void*)d_aff}) if (p) HIPCHECK(hipFree(p));
+    d_x_stage = d_y_stage = nullptr; d_aff = nullptr; stage_chunk = 0;
+    HIPCHECK(hipMalloc(&d_x_stage, chunk * in_elems * sizeof(float)));
+    HIPCHECK(hipMalloc(&d_y_stage, chunk * out_elems * sizeof(float)));
+    HIPCHECK(hipMalloc(&d_aff, (size_t)chunk * 4 * sizeof(float)));
+    stage_chunk = chunk;
+  }
+  if (!d_nonfinite) HIPCHECK(hipMalloc(&d_nonfinite, sizeof(unsigned long long)));
+  HIPCHECK(hipMemsetAsync(d_nonfinite, 0, sizeof(unsigned long long), nullptr));
+  for (int i = 0; i < n; i += stage_chunk) {
+    int c = std::min(stage_chunk, n - i);
+    HIPCHECK(hipMemcpyAsync(d_x_stage, x + (size_t)i * in_elems, c * in_elems * sizeof(float), hipMemcpyHostToDevice, nullptr));
+    float* ain = nullptr;
+    float* aout = nullptr;
+    if (aff_in) { ain = d_aff; HIPCHECK(hipMemcpyAsync(ain, aff_in + 2 * (size_t)i, (size_t)c * 2 * sizeof(float), hipMemcpyHostToDevice, nullptr)); }
+    if (aff_out) { aout = d_aff + 2 * (size_t)stage_chunk; HIPCHECK(hipMemcpyAsync(aout, aff_out + 2 * (size_t)i, (size_t)c * 2 * sizeof(float), hipMemcpyHostToDevice, nullptr)); }
+    int rc = predict_device(d_x_stage, c, ain, aout, d_y_stage, SRCFD_F32, flags, d_nonfinite, nullptr);
+    if (rc) return rc;
+    HIPCHECK(hipMemcpyAsync(y + (size_t)i * out_elems, d_y_stage, c * out_elems * sizeof(float), hipMemcpyDeviceToHost, nullptr));
+    HIPCHECK(hipStreamSynchronize(nullptr));
+  }
+  if (n_nonfinite) {
+    unsigned long long v = 0;
+    HIPCHECK(hipMemcpy(&v, d_nonfinite, sizeof(v), hipMemcpyDeviceToHost));
+    *n_nonfinite = (int64_t)v;
+  }
+  return SRCFD_OK;
+}
+
+static int finish_create(std::unique_ptr<Model>& m, srcfd_model** out) {
+  try {
+    m->desc.infer_shapes();
+    build_plan(m->desc, m->ops, m->pack);
+  } catch (const std::exception& e) {
+    set_error(e.what());
+    return SRCFD_EINVAL;
+  }
+  m->has_fused = m->desc.is_sr_10_400();
+  int rc = m->init_device();
+  if (rc) return rc;
+  if (m->device >= 0 && m->has_fused) {
+    rc = fused_init(*m);
+    if (rc) return rc;
+  }
+  *out = reinterpret_cast<srcfd_model*>(m.release());
+  return SRCFD_OK;
+}
+
+}  // namespace srcfd
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+using srcfd::Model;
+using srcfd::set_error;
+static Model* M(srcfd_model* m) { return reinterpret_cast<Model*>(m); }
+static const Model* M(const srcfd_model* m) { return reinterpret_cast<const Model*>(m); }
+
+extern "C" {
+
+const char* srcfd_last_error(void) { return srcfd::g_last_error.c_str(); }
+const char* srcfd_version(void) { return "srcfd 0.1 (gfx950)"; }
+
+int srcfd_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+
+int srcfd_model_load_h5(const char* encoder_h5, const char* decoder_h5, int device, srcfd_model** out) {
+  if (!out || (!encoder_h5 && !decoder_h5)) { set_error("srcfd_model_load_h5: bad arguments"); return SRCFD_EINVAL; }
+  *out = nullptr;
+  std::unique_ptr<Model> m(new Model());
+  m->device = device;
+  try {
+    if (encoder_h5) srcfd::append_h5_submodel(m->desc, encoder_h5);
+    if (decoder_h5) srcfd::append_h5_submodel(m->desc, decoder_h5);
+  } catch (const srcfd::FileError& e) {
+    set_error(e.msg);
+    return e.code;
+  } catch (const std::exception& e) {
+    set_error(e.what());
+    return SRCFD_EIO;
+  }
+  return srcfd::finish_create(m, out);
+}
+
+int srcfd_model_create(const srcfd_layer* layers, int n_layers, const int in_shape[3], int device, srcfd_model** out) {
+  if (!out || !layers || n_layers <= 0 || !in_shape) { set_error("srcfd_model_create: bad arguments"); return SRCFD_EINVAL; }
+  *out = nullptr;
+  std::unique_ptr<Model> m(new Model());
+  m->device = device;
+  for (int i = 0; i < 3; ++i) m->desc.in_shape[i] = in_shape[i];
+  int cur[3] = {in_shape[0], in_shape[1], in_shape[2]};
+  (void)cur;
+  for (int i = 0; i < n_layers; ++i) {
+    const srcfd_layer& s = layers[i];
+    srcfd::Layer L;
+    L.kind = s.kind; L.act = s.activation; L.kh = s.kh; L.kw = s.kw; L.stride = s.stride > 0 ? s.stride : 1; L.same = s.same_padding;
+    L.cin = s.cin; L.cout = s.cout;
+    for (int k = 0; k < 3; ++k) L.reshape[k] = s.reshape[k];
+    L.name = "layer_" + std::to_string(i);
+    if (s.kind == SRCFD_LAYER_CONV2D || s.kind == SRCFD_LAYER_CONV2D_TRANSPOSE || s.kind == SRCFD_LAYER_DENSE) {
+      if (!s.kernel || s.cin <= 0 || s.cout <= 0) { set_error("layer " + std::to_string(i) + ": missing kernel / channels"); return SRCFD_EINVAL; }
+      if (s.kind == SRCFD_LAYER_DENSE) { L.kh = L.kw = 1; }
+      if (L.kh <= 0 || L.kw <= 0) { set_error("layer " + std::to_string(i) + ": bad kernel size"); return SRCFD_EINVAL; }
+      size_t cnt = (size_t)L.kh * L.kw * s.cin * s.cout;
+      L.kernel.assign(s.kernel, s.kernel + cnt);
+      if (s.bias) L.bias.assign(s.bias, s.bias + s.cout);
+      else L.bias.assign(s.cout, 0.f);
+    }
+    m->desc.layers.push_back(std::move(L));
+  }
+  srcfd::SubModel sub;
+  sub.name = "model"; sub.input_name = "model_input"; sub.first = 0; sub.count = n_layers;
+  m->desc.subs.push_back(sub);
+  return srcfd::finish_create(m, out);
+}
+
+void srcfd_model_destroy(srcfd_model* m) { delete M(m); }
+
+int srcfd_model_input_shape(const srcfd_model* m, int shape[3]) {
+  if (!m || !shape) { set_error("bad arguments"); return SRCFD_EINVAL; }
+  for (int i = 0; i < 3; ++i) shape[i] = M(m)->desc.in_shape[i];
+  return SRCFD_OK;
+}
+int srcfd_model_output_shape(const srcfd_model* m, int shape[3]) {
+  if (!m || !shape) { set_error("bad arguments"); return SRCFD_EINVAL; }
+  for (int i = 0; i < 3; ++i) shape[i] = M(m)->desc.out_shape()[i];
+  return SRCFD_OK;
+}
+int srcfd_model_num_layers(const srcfd_model* m) { return m ? (int)M(m)->desc.layers.size() : SRCFD_EINVAL; }
+
+int srcfd_model_get_layer(const srcfd_model* m, int i, srcfd_layer* layer, char* name, size_t name_len) {
+  if (!m || !layer || i < 0 || i >= (int)M(m)->desc.layers.size()) { set_error("bad arguments"); return SRCFD_EINVAL; }
+  const srcfd::Layer& L = M(m)->desc.layers[i];
+  layer->kind = L.kind; layer->activation = L.act; layer->kh = L.kh; layer->kw = L.kw; layer->stride = L.stride;
+  layer->same_padding = L.same; layer->cin = L.cin; layer->cout = L.cout;
+  for (int k = 0; k < 3; ++k) layer->reshape[k] = L.reshape[k];
+  layer->kernel = L.kernel.empty() ? nullptr : L.kernel.data();
+  layer->bias = L.bias.empty() ? nullptr : L.bias.data();
+  if (name && name_len) { std::snprintf(name, name_len, "%s", L.name.c_str()); }
+  return SRCFD_OK;
+}
+
+int64_t srcfd_model_macs_per_sample(const srcfd_model* m) { return m ? M(m)->desc.macs_per_sample() : 0; }
+
+int srcfd_model_set_precision(srcfd_model* m, int precision) {
+  if (!m || precision < 0 || precision > SRCFD_PREC_F16) { set_error("bad precision"); return SRCFD_EINVAL; }
+  if ((precision == SRCFD_PREC_BF16 || precision == SRCFD_PREC_F16) && !M(m)->has_fused) {
+    set_error("bf16/f16 precision needs the encoder_10+decoder_400 layer graph");
+    return SRCFD_EINVAL;
+  }
+  M(m)->precision = precision;
+  return SRCFD_OK;
+}
+int srcfd_model_get_precision(const srcfd_model* m) { return m ? M(m)->precision : SRCFD_EINVAL; }
+int srcfd_model_has_fused_path(const srcfd_model* m) { return m ? (int)M(m)->has_fused : 0; }
+
+int srcfd_predict(srcfd_model* m, const float* x, int n, const float* in_affine, const float* out_affine, float* y, int flags,
+                  int64_t* n_nonfinite) {
+  if (!m) { set_error("null model"); return SRCFD_EINVAL; }
+  return M(m)->predict_host(x, n, in_affine, out_affine, y, flags, n_nonfinite);
+}
+
+int srcfd_predict_device(srcfd_model* m, const void* x_dev, int n, const float* in_affine_dev, const float* out_affine_dev,
+                         void* y_dev, int out_dtype, int flags, int64_t* nonfinite_dev, void* hip_stream) {
+  if (!m || (n > 0 && (!x_dev || !y_dev))) { set_error("bad arguments"); return SRCFD_EINVAL; }
+  return M(m)->predict_device(x_dev, n, in_affine_dev, out_affine_dev, y_dev, out_dtype, flags,
+                              reinterpret_cast<unsigned long long*>(nonfinite_dev), reinterpret_cast<hipStream_t>(hip_stream));
+}
+
+int srcfd_model_workspace(srcfd_model* m, int n, size_t* bytes) {
+  if (!m) { set_error("null model"); return SRCFD_EINVAL; }
+  int chunk = std::min(std::max(n, 1), M(m)->chunk_cap());
+  if (bytes) *bytes = 2 * (size_t)chunk * M(m)->max_act_elems() * sizeof(float);
+  return chunk;
+}
+
+int srcfd_model_set_profiling(srcfd_model* m, int enable) {
+  if (!m) { set_error("null model"); return SRCFD_EINVAL; }
+  M(m)->profiling = enable != 0;
+  M(m)->prof_used = 0;
+  return SRCFD_OK;
+}
+
+int srcfd_model_get_profile(srcfd_model* m, char* names, size_t names_len, float* ms, int* count, int max_count) {
+  if (!m || !count) { set_error("bad arguments"); return SRCFD_EINVAL; }
+  Model* mm = M(m);
+  if (mm->device < 0) { set_error("host-only handle"); return SRCFD_ENODEV; }
+  HIPCHECK(hipSetDevice(mm->device));
+  HIPCHECK(hipDeviceSynchronize());
+  std::string joined;
+  int n = 0;
+  for (size_t i = 0; i < mm->prof_used && n < max_count; ++i, ++n) {
+    float t = 0.f;
+    HIPCHECK(hipEventElapsedTime(&t, mm->prof_events[i].a, mm->prof_events[i].b));
+    if (ms) ms[n] = t;
+    if (n) joined += '\n';
+    joined += mm->prof_events[i].name;
+  }
+  *count = n;
+  if (names && names_len) std::snprintf(names, names_len, "%s", joined.c_str());
+  return SRCFD_OK;
+}
+
+int srcfd_model_save_h5(const srcfd_model* m, const char* encoder_h5, const char* decoder_h5) {
+  if (!m) { set_error("null model"); return SRCFD_EINVAL; }
+  const Model* mm = M(m);
+  try {
+    const char* paths[2] = {encoder_h5, decoder_h5};
+    int given = (encoder_h5 ? 1 : 0) + (decoder_h5 ? 1 : 0);
+    if (given == 0) { set_error("no output path"); return SRCFD_EINVAL; }
+    if ((int)mm->desc.subs.size() == 1) {
+      srcfd::save_h5_submodel(mm->desc, 0, encoder_h5 ? encoder_h5 : decoder_h5);
+    } else {
+      for (int i = 0; i < 2 && i < (int)mm->desc.subs.size(); ++i)
+        if (paths[i]) srcfd::save_h5_submodel(mm->desc, i, paths[i]);
+    }
+  } catch (const srcfd::FileError& e) {
+    set_error(e.msg);
+    return e.code;
+  }
+  return SRCFD_OK;
+}
+
+}  // extern "C"

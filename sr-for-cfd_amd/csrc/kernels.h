@@ -1,0 +1,30 @@
+// Kernel-side descriptors and launchers shared by engine.hip and the kernel TUs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/srcfd.h"
+
+namespace srcfd {
+
+// Implicit-GEMM descriptor; see the header comment of kernels_fp32.hip.
+struct GemmDesc {
+  int M, N, K, Npad;
+  int MH, MW;          // per-image row grid
+  int TY, TX, CI;      // K = TY*TX*CI
+  int IH, IW;          // input spatial dims (channels = CI)
+  int ay, by, cy;      // iy = my*ay + ty*by + cy
+  int ax, bx, cx;
+  int CO, nphx;        // n -> (phase = n / CO, co = n % CO); phase -> (py = ph / nphx, px = ph % nphx)
+  int OH, OW, OC;      // output tensor dims
+  int os, oy0, ox0;    // oy = my*os + oy0 + py
+  int act;
+};
+
+hipError_t launch_gemm_naive(const GemmDesc& d, const float* X, const float* B, const float* bias, float* Y, hipStream_t s);
+hipError_t launch_gemm_mfma(const GemmDesc& d, const float* X, const float* B, const float* bias, float* Y, hipStream_t s);
+hipError_t launch_standardize(const float* x, float* y, const float* affine, int per_sample, int64_t total, hipStream_t s);
+hipError_t launch_finalize(const float* y, void* out, int out_dtype, const float* affine, int per_sample, int64_t total,
+                           int nan_guard, unsigned long long* nonfinite, hipStream_t s);
+
+}  // namespace srcfd

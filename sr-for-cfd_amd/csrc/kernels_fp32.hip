@@ -1,0 +1,282 @@
+// fp32 kernels of the SR engine (gfx950 only).
+//
+// One implicit-GEMM formulation covers every layer of encoder_10 / decoder_400
+// (sr-ae-conv.ipynb:c162-169, c277-287):
+//   out[row m, col n] = act( bias[n] + sum_k A[m,k] * B[k,n] )
+//   m -> (image, my, mx) on a per-image row grid; k -> (ty, tx, ci)
+//   A[m,k] = X[image, my*ay + ty*by + cy, mx*ax + tx*bx + cx, ci]   (0 outside)
+//   n -> (phase, co); stored at (my*os + oy0 + py(phase), mx*os + ox0 + px(phase), co)
+// Conv2D: ay=stride, by=1, cy=-pad_top.  Conv2DTranspose is split into its
+// stride^2 output phases (ay=1, by=-1): no zero-inserted taps are multiplied.
+// When kernel==stride the phases share one tap and are merged into a single
+// GEMM with N = stride^2*Cout and a pixel-shuffle store.  Dense: 1x1 grid.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace srcfd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  switch (act) {
+    case SRCFD_ACT_SWISH: {
+      // x * sigmoid(x); v_exp_f32 + v_rcp_f32 (<= 2 ulp each)
+      float e = __builtin_amdgcn_exp2f(v * -1.4426950408889634f);
+      return v * __builtin_amdgcn_rcpf(1.0f + e);
+    }
+    case SRCFD_ACT_RELU: return fmaxf(v, 0.f);
+    case SRCFD_ACT_SIGMOID: return 1.0f / (1.0f + __expf(-v));
+    case SRCFD_ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+
+// Accurate variant for the parity path: expf + IEEE division.
+__device__ __forceinline__ float act_apply_precise(float v, int act) {
+  if (act == SRCFD_ACT_SWISH) return v / (1.0f + expf(-v));
+  return act_apply(v, act);
+}
+
+__device__ __forceinline__ void row_decode(const GemmDesc& d, int m, int& img, int& my, int& mx) {
+  int per = d.MH * d.MW;
+  img = m / per;
+  int r = m - img * per;
+  my = r / d.MW;
+  mx = r - my * d.MW;
+}
+
+__device__ __forceinline__ int64_t out_offset(const GemmDesc& d, int img, int my, int mx, int n) {
+  int ph = n / d.CO, co = n - ph * d.CO;
+  int py = ph / d.nphx, px = ph - py * d.nphx;
+  int oy = my * d.os + d.oy0 + py, ox = mx * d.os + d.ox0 + px;
+  return (((int64_t)img * d.OH + oy) * d.OW + ox) * d.OC + co;
+}
+
+// ---------------------------------------------------------------------------
+// bring-up kernel: one thread per output element, sequential f32 FMA chain in
+// (ty,tx,ci) order -- the order oracle/sr_oracle.c uses.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) gemm_naive_f32(GemmDesc d, const float* __restrict__ X,
+                                                       const float* __restrict__ B,
+                                                       const float* __restrict__ bias,
+                                                       float* __restrict__ Y) {
+  int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  int64_t total = (int64_t)d.M * d.N;
+  if (idx >= total) return;
+  int m = (int)(idx / d.N), n = (int)(idx - (int64_t)m * d.N);
+  int img, my, mx;
+  row_decode(d, m, img, my, mx);
+  float acc = bias[n];
+  for (int ty = 0; ty < d.TY; ++ty) {
+    int iy = my * d.ay + ty * d.by + d.cy;
+    if (iy < 0 || iy >= d.IH) continue;
+    for (int tx = 0; tx < d.TX; ++tx) {
+      int ix = mx * d.ax + tx * d.bx + d.cx;
+      if (ix < 0 || ix >= d.IW) continue;
+      const float* xp = X + (((int64_t)img * d.IH + iy) * d.IW + ix) * d.CI;
+      const float* bp = B + (int64_t)((ty * d.TX + tx) * d.CI) * d.Npad + n;
+      for (int ci = 0; ci < d.CI; ++ci) acc = fmaf(xp[ci], bp[(int64_t)ci * d.Npad], acc);
+    }
+  }
+  Y[out_offset(d, img, my, mx, n)] = act_apply_precise(acc, d.act);
+}
+
+// ---------------------------------------------------------------------------
+// f32 MFMA implicit GEMM.  Block = 256 threads = 4 waves; block tile 128 x
+// (32*NB); each wave owns 32 rows x NB tiles of 32 columns
+// (v_mfma_f32_32x32x2_f32: exact f32 products, k-ordered fmaf chain).
+// VEC: CI % 16 == 0, so a 16-deep K slab sits inside one (ty,tx) tap and the
+// A tile is gathered with 16-byte loads.
+// ---------------------------------------------------------------------------
+constexpr int BM = 128, BK = 16, LDA = BK + 1;
+
+template <int NB, bool VEC>
+__global__ void __launch_bounds__(256) gemm_mfma_f32(GemmDesc d, const float* __restrict__ X,
+                                                      const float* __restrict__ B,
+                                                      const float* __restrict__ bias,
+                                                      float* __restrict__ Y) {
+  constexpr int BN = 32 * NB;
+  __shared__ float As[BM * LDA];
+  __shared__ float Bs[BK * BN];
+  __shared__ int row_img[BM], row_my[BM], row_mx[BM];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+  if (tid < BM) {
+    int m = m0 + tid, img = -1, my = 0, mx = 0;
+    if (m < d.M) row_decode(d, m, img, my, mx);
+    row_img[tid] = img; row_my[tid] = my; row_mx[tid] = mx;
+  }
+  __syncthreads();
+
+  f32x16 acc[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  const int K = d.K;
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    // ---- stage A tile [BM][BK] ----
+    if (VEC) {
+      int tap = k0 / d.CI, ci0 = k0 - tap * d.CI;
+      int ty = tap / d.TX, tx = tap - ty * d.TX;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        int row = (tid >> 2) + 64 * j, c4 = tid & 3;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        int img = row_img[row];
+        if (img >= 0) {
+          int iy = row_my[row] * d.ay + ty * d.by + d.cy, ix = row_mx[row] * d.ax + tx * d.bx + d.cx;
+          if (iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW)
+            v = *reinterpret_cast<const float4*>(X + (((int64_t)img * d.IH + iy) * d.IW + ix) * d.CI + ci0 + c4 * 4);
+        }
+        float* dst = As + row * LDA + c4 * 4;
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        int e = tid + 256 * j, row = e >> 4, kk = e & 15, k = k0 + kk;
+        float v = 0.f;
+        int img = row_img[row];
+        if (img >= 0 && k < K) {
+          int tap = k / d.CI, ci = k - tap * d.CI;
+          int ty = tap / d.TX, tx = tap - ty * d.TX;
+          int iy = row_my[row] * d.ay + ty * d.by + d.cy, ix = row_mx[row] * d.ax + tx * d.bx + d.cx;
+          if (iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW)
+            v = X[(((int64_t)img * d.IH + iy) * d.IW + ix) * d.CI + ci];
+        }
+        As[row * LDA + kk] = v;
+      }
+    }
+    // ---- stage B tile [BK][BN] (B is zero-padded to Npad columns) ----
+#pragma unroll
+    for (int e = tid; e < BK * BN; e += 256) {
+      int kk = e / BN, c = e - kk * BN, k = k0 + kk;
+      Bs[e] = (k < K) ? B[(int64_t)k * d.Npad + n0 + c] : 0.f;
+    }
+    __syncthreads();
+    const float* ap = As + (wave * 32 + (lane & 31)) * LDA + (lane >> 5);
+    const float* bp = Bs + (lane >> 5) * BN + (lane & 31);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a = ap[kk];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[kk * BN + 32 * i], acc[i], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias + activation + (pixel-shuffle) store ----
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    int n = n0 + 32 * i + (lane & 31);
+    if (n >= d.N) continue;
+    float bv = bias[n];
+    int ph = n / d.CO, co = n - ph * d.CO;
+    int py = ph / d.nphx, px = ph - py * d.nphx;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      int img = row_img[row];
+      if (img < 0) continue;
+      int oy = row_my[row] * d.os + d.oy0 + py, ox = row_mx[row] * d.os + d.ox0 + px;
+      Y[(((int64_t)img * d.OH + oy) * d.OW + ox) * d.OC + co] = act_apply_precise(acc[i][r] + bv, d.act);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// element-wise pre / post
+// ---------------------------------------------------------------------------
+// x := (x - mean) / std in float32, exactly numpy's float32 arithmetic
+// (standardize_with_stats, PyCFD_ML_accelerated.py:665-668).
+__global__ void __launch_bounds__(256) standardize_f32(const float* __restrict__ x, float* __restrict__ y,
+                                                        const float* __restrict__ affine, int per_sample, int64_t total) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  float v = x[i];
+  if (affine) {
+    int s = (int)(i / per_sample);
+    float mean = affine[2 * s], sd = affine[2 * s + 1];
+    if (sd == 0.f) sd = 1e-8f;
+    v = __fdiv_rn(__fsub_rn(v, mean), sd);
+  }
+  y[i] = v;
+}
+
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+  __bf16 h = (__bf16)f;  // v_cvt_pk_bf16_f32: RNE, NaN stays NaN
+  return __builtin_bit_cast(unsigned short, h);
+}
+
+// y := y * std + mean (two roundings, inverse_standardize PyCFD...:671-673), then
+// the NaN/Inf zero-fill of PyCFD...:869-876, then the output cast.
+template <int OUT>  // 0 f32, 1 bf16, 2 f16
+__global__ void __launch_bounds__(256) finalize_out(const float* __restrict__ y, void* __restrict__ out,
+                                                     const float* __restrict__ affine, int per_sample, int64_t total,
+                                                     int nan_guard, unsigned long long* __restrict__ nonfinite) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  bool bad = false;
+  if (i < total) {
+    float v = y[i];
+    if (affine) {
+      int s = (int)(i / per_sample);
+      v = __fadd_rn(__fmul_rn(v, affine[2 * s + 1]), affine[2 * s]);
+    }
+    if (nan_guard && !(fabsf(v) <= 3.402823466e38f)) { bad = true; v = 0.f; }
+    if (OUT == 0) ((float*)out)[i] = v;
+    else if (OUT == 1) ((unsigned short*)out)[i] = f32_to_bf16_bits(v);
+    else ((_Float16*)out)[i] = (_Float16)v;
+  }
+  if (nan_guard && nonfinite) {
+    unsigned long long mask = __ballot(bad);
+    if (mask && (threadIdx.x & 63) == 0) atomicAdd(nonfinite, (unsigned long long)__popcll(mask));
+  }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+hipError_t launch_gemm_naive(const GemmDesc& d, const float* X, const float* B, const float* bias, float* Y, hipStream_t s) {
+  int64_t total = (int64_t)d.M * d.N;
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL(gemm_naive_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d, X, B, bias, Y);
+  return hipGetLastError();
+}
+
+hipError_t launch_gemm_mfma(const GemmDesc& d, const float* X, const float* B, const float* bias, float* Y, hipStream_t s) {
+  if (d.M == 0 || d.N == 0) return hipSuccess;
+  bool vec = (d.CI % 16 == 0) && d.K > 0;
+  int nb = (d.Npad % 128 == 0) ? 4 : ((d.Npad % 64 == 0) ? 2 : 1);
+  dim3 grid((d.M + BM - 1) / BM, d.Npad / (32 * nb));
+#define GO(NBV, VECV) hipLaunchKernelGGL((gemm_mfma_f32<NBV, VECV>), grid, dim3(256), 0, s, d, X, B, bias, Y)
+  if (nb == 4) { if (vec) GO(4, true); else GO(4, false); }
+  else if (nb == 2) { if (vec) GO(2, true); else GO(2, false); }
+  else { if (vec) GO(1, true); else GO(1, false); }
+#undef GO
+  return hipGetLastError();
+}
+
+hipError_t launch_standardize(const float* x, float* y, const float* affine, int per_sample, int64_t total, hipStream_t s) {
+  if (total == 0) return hipSuccess;
+  hipLaunchKernelGGL(standardize_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, y, affine, per_sample, total);
+  return hipGetLastError();
+}
+
+hipError_t launch_finalize(const float* y, void* out, int out_dtype, const float* affine, int per_sample, int64_t total,
+                           int nan_guard, unsigned long long* nonfinite, hipStream_t s) {
+  if (total == 0) return hipSuccess;
+  dim3 grid((unsigned)((total + 255) / 256));
+  if (out_dtype == SRCFD_F32) hipLaunchKernelGGL(finalize_out<0>, grid, dim3(256), 0, s, y, out, affine, per_sample, total, nan_guard, nonfinite);
+  else if (out_dtype == SRCFD_BF16) hipLaunchKernelGGL(finalize_out<1>, grid, dim3(256), 0, s, y, out, affine, per_sample, total, nan_guard, nonfinite);
+  else if (out_dtype == SRCFD_F16) hipLaunchKernelGGL(finalize_out<2>, grid, dim3(256), 0, s, y, out, affine, per_sample, total, nan_guard, nonfinite);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
+}  // namespace srcfd

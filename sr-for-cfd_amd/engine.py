@@ -1,0 +1,242 @@
+"""Python handle over ``srcfd_model`` (include/srcfd.h).
+
+``SRModel`` is the host-side object the Keras-compatible surface
+(``keras_compat.py``) and the solver harness (``pipeline.py``) sit on.  It
+replaces what ``tf.keras.models.load_model`` + ``SuperResolutionAE`` +
+``Model.predict`` do in PyCFD_ML_accelerated.py:831-833,858.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib as L
+
+PRECISIONS = {"fp32": L.PREC_FP32, "float32": L.PREC_FP32, "bf16": L.PREC_BF16, "bfloat16": L.PREC_BF16,
+              "fp32_naive": L.PREC_FP32_NAIVE, "f16": L.PREC_F16, "fp16": L.PREC_F16, "float16": L.PREC_F16}
+_ACT = {"linear": L.ACT_LINEAR, None: L.ACT_LINEAR, "swish": L.ACT_SWISH, "silu": L.ACT_SWISH, "relu": L.ACT_RELU,
+        "sigmoid": L.ACT_SIGMOID, "tanh": L.ACT_TANH}
+_KIND = {"conv2d": L.LAYER_CONV2D, "conv2d_transpose": L.LAYER_CONV2D_TRANSPOSE, "dense": L.LAYER_DENSE,
+         "flatten": L.LAYER_FLATTEN, "reshape": L.LAYER_RESHAPE}
+
+
+def device_count() -> int:
+    return int(L.lib.srcfd_device_count())
+
+
+def layers_from_weights(enc_w: Optional[Dict[str, np.ndarray]], dec_w: Optional[Dict[str, np.ndarray]]) -> List[dict]:
+    """Layer specs of encoder_10 and/or decoder_400 (sr-ae-conv.ipynb:c162-169,
+    c277-287) from ``{'<layer>/kernel', '<layer>/bias'}`` dicts."""
+    specs: List[dict] = []
+    if enc_w is not None:
+        specs += [
+            dict(kind="conv2d", k=3, stride=2, same=True, act="swish", w=enc_w["conv2d/kernel"], b=enc_w["conv2d/bias"]),
+            dict(kind="conv2d", k=3, stride=1, same=True, act="swish", w=enc_w["conv2d_1/kernel"], b=enc_w["conv2d_1/bias"]),
+            dict(kind="flatten"),
+            dict(kind="dense", act="swish", w=enc_w["dense/kernel"], b=enc_w["dense/bias"]),
+            dict(kind="dense", act="linear", w=enc_w["latent_vector/kernel"], b=enc_w["latent_vector/bias"]),
+        ]
+    if dec_w is not None:
+        specs += [dict(kind="dense", act="swish", w=dec_w["dense_1/kernel"], b=dec_w["dense_1/bias"]),
+                  dict(kind="reshape", shape=(12, 12, 256))]
+        for i, k in enumerate((3, 2, 2, 2, 2)):
+            name = "conv2d_transpose" + ("" if i == 0 else f"_{i}")
+            specs.append(dict(kind="conv2d_transpose", k=k, stride=2, same=False, act="swish",
+                              w=dec_w[f"{name}/kernel"], b=dec_w[f"{name}/bias"]))
+        specs.append(dict(kind="conv2d", k=3, stride=1, same=True, act="linear",
+                          w=dec_w["output_image_400/kernel"], b=dec_w["output_image_400/bias"]))
+    return specs
+
+
+class SRModel:
+    """Owns one ``srcfd_model*``.  ``device=None`` -> GPU 0 when one exists,
+    else a host-only handle (shape / weight queries; predict raises)."""
+
+    def __init__(self, handle: C.c_void_p, device: int):
+        self._h = handle
+        self.device = device
+        self._keep = None
+
+    # -- construction -------------------------------------------------------
+    @staticmethod
+    def _pick_device(device) -> int:
+        if device is None:
+            return 0 if device_count() > 0 else -1
+        return int(device)
+
+    @classmethod
+    def load_h5(cls, encoder_h5=None, decoder_h5=None, device=None) -> "SRModel":
+        dev = cls._pick_device(device)
+        h = C.c_void_p()
+        L.check(L.lib.srcfd_model_load_h5(L.enc(encoder_h5) if encoder_h5 else None,
+                                          L.enc(decoder_h5) if decoder_h5 else None, dev, C.byref(h)))
+        return cls(h, dev)
+
+    @classmethod
+    def from_layers(cls, specs: Sequence[dict], in_shape: Tuple[int, int, int], device=None) -> "SRModel":
+        dev = cls._pick_device(device)
+        arr = (L.Layer * len(specs))()
+        keep = []
+        for i, s in enumerate(specs):
+            l = arr[i]
+            l.kind = _KIND[s["kind"]]
+            l.activation = _ACT[s.get("act", "linear")]
+            l.kh = l.kw = int(s.get("k", 1))
+            l.stride = int(s.get("stride", 1))
+            l.same_padding = int(bool(s.get("same", False)))
+            if "shape" in s:
+                for j in range(3):
+                    l.reshape[j] = int(s["shape"][j])
+            if "w" in s:
+                w = np.ascontiguousarray(s["w"], dtype=np.float32)
+                b = np.ascontiguousarray(s["b"], dtype=np.float32)
+                keep += [w, b]
+                if l.kind == L.LAYER_DENSE:
+                    l.cin, l.cout = w.shape
+                elif l.kind == L.LAYER_CONV2D:
+                    l.kh, l.kw, l.cin, l.cout = w.shape
+                else:
+                    l.kh, l.kw, l.cout, l.cin = w.shape
+                l.kernel = w.ctypes.data_as(C.POINTER(C.c_float))
+                l.bias = b.ctypes.data_as(C.POINTER(C.c_float))
+        shp = (C.c_int * 3)(*in_shape)
+        h = C.c_void_p()
+        L.check(L.lib.srcfd_model_create(arr, len(specs), shp, dev, C.byref(h)))
+        return cls(h, dev)
+
+    @classmethod
+    def from_weights(cls, enc_w, dec_w, device=None) -> "SRModel":
+        in_shape = (10, 10, 1) if enc_w is not None else (1, 1, 50)
+        return cls.from_layers(layers_from_weights(enc_w, dec_w), in_shape, device)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib.srcfd_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- queries ------------------------------------------------------------
+    @property
+    def input_shape(self) -> Tuple[int, int, int]:
+        s = (C.c_int * 3)()
+        L.check(L.lib.srcfd_model_input_shape(self._h, s))
+        return tuple(s)
+
+    @property
+    def output_shape(self) -> Tuple[int, int, int]:
+        s = (C.c_int * 3)()
+        L.check(L.lib.srcfd_model_output_shape(self._h, s))
+        return tuple(s)
+
+    @property
+    def macs_per_sample(self) -> int:
+        return int(L.lib.srcfd_model_macs_per_sample(self._h))
+
+    @property
+    def has_fused_path(self) -> bool:
+        return bool(L.lib.srcfd_model_has_fused_path(self._h))
+
+    @property
+    def precision(self) -> str:
+        p = L.lib.srcfd_model_get_precision(self._h)
+        return {L.PREC_FP32: "fp32", L.PREC_BF16: "bf16", L.PREC_FP32_NAIVE: "fp32_naive", L.PREC_F16: "f16"}[p]
+
+    @precision.setter
+    def precision(self, name: str):
+        L.check(L.lib.srcfd_model_set_precision(self._h, PRECISIONS[name]))
+
+    def layers(self) -> List[dict]:
+        out = []
+        for i in range(L.check(L.lib.srcfd_model_num_layers(self._h))):
+            l = L.Layer()
+            name = C.create_string_buffer(128)
+            L.check(L.lib.srcfd_model_get_layer(self._h, i, C.byref(l), name, len(name)))
+            d = dict(name=name.value.decode(), kind=l.kind, activation=l.activation, kh=l.kh, kw=l.kw, stride=l.stride,
+                     same=bool(l.same_padding), cin=l.cin, cout=l.cout, reshape=tuple(l.reshape))
+            if l.kernel:
+                if l.kind == L.LAYER_DENSE:
+                    shape = (l.cin, l.cout)
+                elif l.kind == L.LAYER_CONV2D:
+                    shape = (l.kh, l.kw, l.cin, l.cout)
+                else:
+                    shape = (l.kh, l.kw, l.cout, l.cin)
+                d["kernel"] = np.ctypeslib.as_array(l.kernel, shape=(int(np.prod(shape)),)).reshape(shape).copy()
+                d["bias"] = np.ctypeslib.as_array(l.bias, shape=(l.cout,)).copy()
+            out.append(d)
+        return out
+
+    def weights(self) -> Dict[str, np.ndarray]:
+        w = {}
+        for d in self.layers():
+            if "kernel" in d:
+                w[f"{d['name']}/kernel"] = d["kernel"]
+                w[f"{d['name']}/bias"] = d["bias"]
+        return w
+
+    def save_h5(self, encoder_h5=None, decoder_h5=None):
+        L.check(L.lib.srcfd_model_save_h5(self._h, L.enc(encoder_h5) if encoder_h5 else None,
+                                          L.enc(decoder_h5) if decoder_h5 else None))
+
+    # -- forward ------------------------------------------------------------
+    def predict(self, x: np.ndarray, in_affine=None, out_affine=None, nan_guard: bool = False,
+                return_nonfinite: bool = False):
+        """numpy in / numpy out, like ``Model.predict`` (PyCFD...:858)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        ih, iw, ic = self.input_shape
+        if x.ndim == 2 and ih == 1 and iw == 1:
+            x = x.reshape(x.shape[0], 1, 1, ic)
+        if x.ndim != 4 or x.shape[1:] != (ih, iw, ic):
+            raise ValueError(f"input shape {x.shape} incompatible with model input (None, {ih}, {iw}, {ic})")
+        n = x.shape[0]
+        oh, ow, oc = self.output_shape
+        y = np.empty((n, oh, ow, oc), dtype=np.float32)
+
+        def aff(a):
+            if a is None:
+                return None, None
+            a = np.ascontiguousarray(a, dtype=np.float32).reshape(n, 2)
+            return a, a.ctypes.data_as(C.c_void_p)
+
+        ain, pin = aff(in_affine)
+        aout, pout = aff(out_affine)
+        bad = C.c_int64(0)
+        L.check(L.lib.srcfd_predict(self._h, x.ctypes.data_as(C.c_void_p), n, pin, pout, y.ctypes.data_as(C.c_void_p),
+                                    L.FLAG_NAN_GUARD if nan_guard else 0, C.byref(bad)))
+        if return_nonfinite:
+            return y, int(bad.value)
+        return y
+
+    def predict_device(self, x, y, in_affine=None, out_affine=None, nan_guard=False, nonfinite=None, stream=None):
+        """Device-resident forward on torch CUDA tensors (plumbing only):
+        x float32 (n,h,w,c); y float32/bfloat16/float16 (n,oh,ow,oc); affines
+        float32 (n,2).  Enqueues on ``stream`` (torch stream) or the current one."""
+        import torch
+
+        if not (x.is_cuda and y.is_cuda and x.is_contiguous() and y.is_contiguous()):
+            raise ValueError("predict_device needs contiguous CUDA tensors")
+        if x.dtype != torch.float32:
+            raise ValueError("x must be float32")
+        dt = {torch.float32: L.F32, torch.bfloat16: L.BF16, torch.float16: L.F16}[y.dtype]
+        n = x.shape[0]
+        st = stream if stream is not None else torch.cuda.current_stream(x.device)
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+        L.check(L.lib.srcfd_predict_device(self._h, p(x), n, p(in_affine), p(out_affine), p(y), dt,
+                                           L.FLAG_NAN_GUARD if nan_guard else 0, p(nonfinite), C.c_void_p(st.cuda_stream)))
+
+    def set_profiling(self, on: bool):
+        L.check(L.lib.srcfd_model_set_profiling(self._h, int(on)))
+
+    def get_profile(self) -> List[Tuple[str, float]]:
+        names = C.create_string_buffer(1 << 16)
+        ms = (C.c_float * 4096)()
+        cnt = C.c_int(0)
+        L.check(L.lib.srcfd_model_get_profile(self._h, names, len(names), ms, C.byref(cnt), 4096))
+        ns = names.value.decode().split("\n") if cnt.value else []
+        return [(ns[i], float(ms[i])) for i in range(cnt.value)]

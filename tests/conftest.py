@@ -1,0 +1,59 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+ENCODER_H5 = os.path.join(GOLDEN, "vanilla_encoder10_to_400_swish_trained_upto_700_multiBC.h5")
+STATS_TXT = os.path.join(GOLDEN, "standardization_stats_10to400_swish_trained_upto_700_multiBC.txt")
+COARSE = {
+    "bfs_Re400": "coarse_bfs_Re400.h5",
+    "ldc_Re800_single": "coarse_ldc_Re800_single_lid.h5",
+    "ldc_Re1000_single": "coarse_ldc_Re1000_single_lid.h5",
+    "ldc_Re800_double": "coarse_ldc_Re800_double_lid.h5",
+    "ldc_Re1000_double": "coarse_ldc_Re1000_double_lid.h5",
+}
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def srcfd():
+    import srcfd_amd
+    return srcfd_amd
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import sr_oracle
+    return sr_oracle
+
+
+@pytest.fixture(scope="session")
+def enc_weights(srcfd):
+    """The real multiBC encoder weights, read through libsrcfd's HDF5 reader."""
+    m = srcfd.SRModel.load_h5(ENCODER_H5, None, device=-1)
+    return m.weights()
+
+
+@pytest.fixture(scope="session")
+def dec_weights(oracle):
+    """Synthetic decoder (the reference's decoder .h5 files are absent:
+    .MISSING_LARGE_BLOBS:29-34), variance-preserving init, seed 1."""
+    return oracle.synthetic_decoder(1)
+
+
+@pytest.fixture(scope="session")
+def coarse_cases(srcfd):
+    return {k: srcfd.read_coarse_fields(os.path.join(GOLDEN, v)) for k, v in COARSE.items()}
+
+
+def require_gpu(srcfd):
+    if srcfd.device_count() < 1:
+        pytest.fail("gpu-marked test on a box without a HIP device")

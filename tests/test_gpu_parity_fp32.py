@@ -1,0 +1,159 @@
+"""GPU parity of the f32 engine (through the C ABI) against the float64 oracle.
+
+Tolerance: relative L2 ||y-ref||/||ref|| per sample, max over the
+set, <= 1e-5 on the standardised output for the f32 paths.
+"""
+import numpy as np
+import pytest
+
+from conftest import ENCODER_H5, STATS_TXT, require_gpu
+
+pytestmark = pytest.mark.gpu
+TOL_FP32 = 1e-5
+
+
+def _coarse_batch(coarse_cases, srcfd):
+    """(15,10,10,1) standardised real coarse fields: 5 cases x (u,v,p)."""
+    lr, _ = srcfd.load_stats(STATS_TXT, 10, 400)
+    xs = []
+    for case in coarse_cases.values():
+        for c in ("u", "v", "p"):
+            x = case[c].astype(np.float32)
+            xs.append(((x - lr[c][0]) / lr[c][1]).astype(np.float32))
+    return np.stack(xs)[..., None]
+
+
+@pytest.mark.parametrize("precision", ["fp32_naive", "fp32"])
+def test_full_model_real_coarse_fields(srcfd, oracle, enc_weights, dec_weights, coarse_cases, precision):
+    require_gpu(srcfd)
+    x = _coarse_batch(coarse_cases, srcfd)
+    m = srcfd.SRModel.from_weights(enc_weights, dec_weights, device=0)
+    m.precision = precision
+    y = m.predict(x)
+    ref = oracle.superres_forward(x, enc_weights, dec_weights, np.float64)
+    assert y.shape == (15, 400, 400, 1) and y.dtype == np.float32
+    err = oracle.rel_l2(y, ref)
+    print(f"{precision}: rel L2 vs f64 oracle = {err:.3e}")
+    assert err <= TOL_FP32
+
+
+@pytest.mark.parametrize("precision", ["fp32_naive", "fp32"])
+def test_encoder_latents_real_weights(srcfd, oracle, enc_weights, coarse_cases, precision):
+    """Encoder half alone (the only half whose trained weights exist)."""
+    require_gpu(srcfd)
+    x = _coarse_batch(coarse_cases, srcfd)
+    m = srcfd.SRModel.load_h5(ENCODER_H5, None, device=0)
+    m.precision = precision
+    z = m.predict(x)
+    ref = oracle.encoder_forward(x, enc_weights, np.float64)
+    assert z.shape == (15, 1, 1, 50)
+    assert oracle.rel_l2(z.reshape(15, -1), ref) <= TOL_FP32
+
+
+LAYER_CASES = [
+    # name, spec builder args: kind, k, stride, same, cin, cout, in_hw
+    ("conv_same_s2_asym_pad", "conv2d", 3, 2, True, 1, 64, (10, 10)),
+    ("conv_same_s1", "conv2d", 3, 1, True, 64, 128, (5, 5)),
+    ("conv_same_s2_odd_in", "conv2d", 3, 2, True, 3, 5, (7, 9)),
+    ("conv_valid", "conv2d", 3, 1, False, 4, 6, (8, 8)),
+    ("conv_out_8_1", "conv2d", 3, 1, True, 8, 1, (40, 40)),
+    ("convT_3x3_s2_overlap", "conv2d_transpose", 3, 2, False, 32, 16, (6, 6)),
+    ("convT_2x2_s2", "conv2d_transpose", 2, 2, False, 16, 8, (9, 11)),
+    ("convT_2x2_s2_cin_odd", "conv2d_transpose", 2, 2, False, 5, 3, (4, 4)),
+    ("convT_4x4_s2", "conv2d_transpose", 4, 2, False, 16, 4, (5, 5)),
+]
+
+
+@pytest.mark.parametrize("precision", ["fp32_naive", "fp32"])
+@pytest.mark.parametrize("case", LAYER_CASES, ids=[c[0] for c in LAYER_CASES])
+def test_single_layers(srcfd, oracle, case, precision):
+    require_gpu(srcfd)
+    _, kind, k, stride, same, cin, cout, (h, w) = case
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(case[0].encode()))
+    if kind == "conv2d":
+        wt = rng.standard_normal((k, k, cin, cout)).astype(np.float32) / np.sqrt(k * k * cin)
+    else:
+        wt = rng.standard_normal((k, k, cout, cin)).astype(np.float32) / np.sqrt(cin)
+    b = rng.standard_normal(cout).astype(np.float32) * 0.1
+    x = rng.standard_normal((3, h, w, cin)).astype(np.float32)
+    m = srcfd.SRModel.from_layers([dict(kind=kind, k=k, stride=stride, same=same, act="swish", w=wt, b=b)], (h, w, cin), device=0)
+    m.precision = precision
+    y = m.predict(x)
+    xd = x.astype(np.float64)
+    if kind == "conv2d":
+        ref = oracle.conv2d(xd, wt, b, stride, "same" if same else "valid", "swish")
+    else:
+        ref = oracle.conv2d_transpose(xd, wt, b, stride, "valid", "swish")
+    assert y.shape == ref.shape
+    assert oracle.rel_l2(y, ref) <= TOL_FP32
+
+
+def test_dense_flatten_reshape_chain(srcfd, oracle):
+    require_gpu(srcfd)
+    rng = np.random.default_rng(5)
+    w1 = rng.standard_normal((75, 50)).astype(np.float32) / 8
+    b1 = rng.standard_normal(50).astype(np.float32) * 0.1
+    w2 = rng.standard_normal((50, 48)).astype(np.float32) / 7
+    b2 = rng.standard_normal(48).astype(np.float32) * 0.1
+    specs = [dict(kind="flatten"), dict(kind="dense", act="swish", w=w1, b=b1), dict(kind="dense", act="linear", w=w2, b=b2),
+             dict(kind="reshape", shape=(4, 4, 3))]
+    x = rng.standard_normal((7, 5, 5, 3)).astype(np.float32)
+    for prec in ("fp32_naive", "fp32"):
+        m = srcfd.SRModel.from_layers(specs, (5, 5, 3), device=0)
+        m.precision = prec
+        y = m.predict(x)
+        ref = oracle.dense(oracle.dense(x.reshape(7, -1).astype(np.float64), w1, b1, "swish"), w2, b2, "linear").reshape(7, 4, 4, 3)
+        assert y.shape == (7, 4, 4, 3)
+        assert oracle.rel_l2(y, ref) <= TOL_FP32
+
+
+def test_affine_pre_post_matches_numpy_float32_bitwise(srcfd):
+    """standardize / inverse_standardize fused on device must equal numpy's
+    float32 arithmetic bit for bit (PyCFD_ML_accelerated.py:665-673)."""
+    require_gpu(srcfd)
+    rng = np.random.default_rng(3)
+    n = 6
+    x = rng.standard_normal((n, 4, 4, 2)).astype(np.float32)
+    # identity network: 1x1 conv with identity kernel, linear
+    wt = np.eye(2, dtype=np.float32).reshape(1, 1, 2, 2)
+    m = srcfd.SRModel.from_layers([dict(kind="conv2d", k=1, stride=1, same=True, act="linear", w=wt, b=np.zeros(2, np.float32))], (4, 4, 2), device=0)
+    ain = np.stack([rng.standard_normal(n) * 0.1, rng.uniform(0.05, 0.3, n)], 1).astype(np.float32)
+    ain[2, 1] = 0.0  # std == 0 -> 1e-8
+    aout = np.stack([rng.standard_normal(n) * 0.1, rng.uniform(0.05, 0.3, n)], 1).astype(np.float32)
+    y = m.predict(x, in_affine=ain, out_affine=aout)
+    for i in range(n):
+        sd = np.float32(1e-8) if ain[i, 1] == 0 else ain[i, 1]
+        xn = (x[i] - ain[i, 0]) / sd
+        ref = xn * aout[i, 1] + aout[i, 0]
+        assert ref.dtype == np.float32
+        np.testing.assert_array_equal(y[i].view(np.uint32), ref.view(np.uint32))
+
+
+def test_nan_guard_counts_and_zero_fills(srcfd):
+    require_gpu(srcfd)
+    wt = np.eye(1, dtype=np.float32).reshape(1, 1, 1, 1)
+    m = srcfd.SRModel.from_layers([dict(kind="conv2d", k=1, stride=1, same=True, act="linear", w=wt, b=np.zeros(1, np.float32))], (8, 8, 1), device=0)
+    x = np.ones((2, 8, 8, 1), np.float32)
+    x[0, 1, 1, 0] = np.nan
+    x[1, 2, 3, 0] = np.inf
+    x[1, 5, 5, 0] = -np.inf
+    y, bad = m.predict(x, nan_guard=True, return_nonfinite=True)
+    assert bad == 3
+    assert np.isfinite(y).all() and y[0, 1, 1, 0] == 0 and y[1, 2, 3, 0] == 0 and y[1, 5, 5, 0] == 0
+    y2, bad2 = m.predict(x, nan_guard=False, return_nonfinite=True)
+    assert bad2 == 0 and np.isnan(y2[0, 1, 1, 0]) and np.isinf(y2[1, 2, 3, 0])
+
+
+def test_empty_and_ragged_batches(srcfd, oracle, enc_weights):
+    require_gpu(srcfd)
+    m = srcfd.SRModel.load_h5(ENCODER_H5, None, device=0)
+    assert m.predict(np.zeros((0, 10, 10, 1), np.float32)).shape == (0, 1, 1, 50)
+    rng = np.random.default_rng(11)
+    for n in (1, 2, 129, 257):  # not multiples of the 128-row tile, crosses the 256 staging chunk
+        x = rng.standard_normal((n, 10, 10, 1)).astype(np.float32)
+        z = m.predict(x).reshape(n, 50)
+        ref = oracle.encoder_forward(x, enc_weights, np.float64)
+        assert oracle.rel_l2(z, ref) <= TOL_FP32
+    with pytest.raises(ValueError):
+        m.predict(np.zeros((1, 9, 10, 1), np.float32))
