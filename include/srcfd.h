@@ -63,6 +63,7 @@ typedef struct {
   int reshape[3];  /* RESHAPE target (h,w,c) */
   const float* kernel;
   const float* bias;
+  const char* name; /* optional Keras layer name (used by srcfd_model_save_h5); NULL -> layer_<i> */
 } srcfd_layer;
 
 typedef struct srcfd_model srcfd_model;

@@ -35,6 +35,7 @@ class Layer(C.Structure):
         ("cin", C.c_int), ("cout", C.c_int),
         ("reshape", C.c_int * 3),
         ("kernel", C.POINTER(C.c_float)), ("bias", C.POINTER(C.c_float)),
+        ("name", C.c_char_p),
     ]
 
 

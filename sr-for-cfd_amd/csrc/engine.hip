@@ -368,7 +368,7 @@ int srcfd_model_create(const srcfd_layer* layers, int n_layers, const int in_sha
     L.kind = s.kind; L.act = s.activation; L.kh = s.kh; L.kw = s.kw; L.stride = s.stride > 0 ? s.stride : 1; L.same = s.same_padding;
     L.cin = s.cin; L.cout = s.cout;
     for (int k = 0; k < 3; ++k) L.reshape[k] = s.reshape[k];
-    L.name = "layer_" + std::to_string(i);
+    L.name = (s.name && *s.name) ? std::string(s.name) : "layer_" + std::to_string(i);
     if (s.kind == SRCFD_LAYER_CONV2D || s.kind == SRCFD_LAYER_CONV2D_TRANSPOSE || s.kind == SRCFD_LAYER_DENSE) {
       if (!s.kernel || s.cin <= 0 || s.cout <= 0) { set_error("layer " + std::to_string(i) + ": missing kernel / channels"); return SRCFD_EINVAL; }
       if (s.kind == SRCFD_LAYER_DENSE) { L.kh = L.kw = 1; }
@@ -408,6 +408,7 @@ int srcfd_model_get_layer(const srcfd_model* m, int i, srcfd_layer* layer, char*
   for (int k = 0; k < 3; ++k) layer->reshape[k] = L.reshape[k];
   layer->kernel = L.kernel.empty() ? nullptr : L.kernel.data();
   layer->bias = L.bias.empty() ? nullptr : L.bias.data();
+  layer->name = L.name.c_str();
   if (name && name_len) { std::snprintf(name, name_len, "%s", L.name.c_str()); }
   return SRCFD_OK;
 }

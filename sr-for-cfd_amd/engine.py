@@ -32,20 +32,20 @@ def layers_from_weights(enc_w: Optional[Dict[str, np.ndarray]], dec_w: Optional[
     specs: List[dict] = []
     if enc_w is not None:
         specs += [
-            dict(kind="conv2d", k=3, stride=2, same=True, act="swish", w=enc_w["conv2d/kernel"], b=enc_w["conv2d/bias"]),
-            dict(kind="conv2d", k=3, stride=1, same=True, act="swish", w=enc_w["conv2d_1/kernel"], b=enc_w["conv2d_1/bias"]),
-            dict(kind="flatten"),
-            dict(kind="dense", act="swish", w=enc_w["dense/kernel"], b=enc_w["dense/bias"]),
-            dict(kind="dense", act="linear", w=enc_w["latent_vector/kernel"], b=enc_w["latent_vector/bias"]),
+            dict(kind="conv2d", name="conv2d", k=3, stride=2, same=True, act="swish", w=enc_w["conv2d/kernel"], b=enc_w["conv2d/bias"]),
+            dict(kind="conv2d", name="conv2d_1", k=3, stride=1, same=True, act="swish", w=enc_w["conv2d_1/kernel"], b=enc_w["conv2d_1/bias"]),
+            dict(kind="flatten", name="flatten"),
+            dict(kind="dense", name="dense", act="swish", w=enc_w["dense/kernel"], b=enc_w["dense/bias"]),
+            dict(kind="dense", name="latent_vector", act="linear", w=enc_w["latent_vector/kernel"], b=enc_w["latent_vector/bias"]),
         ]
     if dec_w is not None:
-        specs += [dict(kind="dense", act="swish", w=dec_w["dense_1/kernel"], b=dec_w["dense_1/bias"]),
-                  dict(kind="reshape", shape=(12, 12, 256))]
+        specs += [dict(kind="dense", name="dense_1", act="swish", w=dec_w["dense_1/kernel"], b=dec_w["dense_1/bias"]),
+                  dict(kind="reshape", name="reshape", shape=(12, 12, 256))]
         for i, k in enumerate((3, 2, 2, 2, 2)):
             name = "conv2d_transpose" + ("" if i == 0 else f"_{i}")
-            specs.append(dict(kind="conv2d_transpose", k=k, stride=2, same=False, act="swish",
+            specs.append(dict(kind="conv2d_transpose", name=name, k=k, stride=2, same=False, act="swish",
                               w=dec_w[f"{name}/kernel"], b=dec_w[f"{name}/bias"]))
-        specs.append(dict(kind="conv2d", k=3, stride=1, same=True, act="linear",
+        specs.append(dict(kind="conv2d", name="output_image_400", k=3, stride=1, same=True, act="linear",
                           w=dec_w["output_image_400/kernel"], b=dec_w["output_image_400/bias"]))
     return specs
 
@@ -86,6 +86,10 @@ class SRModel:
             l.kh = l.kw = int(s.get("k", 1))
             l.stride = int(s.get("stride", 1))
             l.same_padding = int(bool(s.get("same", False)))
+            if s.get("name"):
+                nm = s["name"].encode()
+                keep.append(nm)
+                l.name = nm
             if "shape" in s:
                 for j in range(3):
                     l.reshape[j] = int(s["shape"][j])
