@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Headline benchmark: batched super-resolution inference, BASELINE.json config 2.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one pass of the SR hot path over one batch of 256 synthetic fields
+(256 x (10,10,3) -> (400,400,3) = 768 single-channel samples through
+encoder_10 + decoder_400) per GPU, inputs resident in HBM, including the
+per-channel standardise / de-standardise / NaN guard the reference does around
+`predict` (PyCFD_ML_accelerated.py:841-876).  Weak scaling: every rank
+processes its own 256 fields, no data-path collective.
+
+Prints ONE JSON line (rank 0).  `roofline` is measured live with HIP events on
+the launch stream around the dominant kernel; `cpu_baseline` times the torch-CPU
+(oneDNN) restatement of the same network on the host cores (rank 0, N=1 only).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+ENCODER_H5 = os.path.join(GOLDEN, "vanilla_encoder10_to_400_swish_trained_upto_700_multiBC.h5")
+STATS_TXT = os.path.join(GOLDEN, "standardization_stats_10to400_swish_trained_upto_700_multiBC.txt")
+
+FIELDS = 256                      # BASELINE.json config 2
+MACS_PER_SAMPLE = 140_024_128
+PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16/f16 MFMA (MI355X_MICROARCH.md)
+PEAK_FP32_TFLOPS = 157.3          # f32-input MFMA
+PEAK_HBM_GBS = 8000.0
+
+
+def build_inputs(fields, seed, stats_lr, stats_hr):
+    """x ~ N(0,1) in standardised space, mapped back to physical
+    units so the engine's fused standardise does real work.  Sample order is
+    field-major, component-minor: sample 3*f + c."""
+    rng = np.random.default_rng(seed)
+    xs = rng.standard_normal((fields, 10, 10, 3)).astype(np.float32)
+    comps = ("u", "v", "p")
+    lr = np.array([stats_lr[c] for c in comps], np.float32)  # (3,2) mean,std
+    hr = np.array([stats_hr[c] for c in comps], np.float32)
+    raw = xs * lr[:, 1] + lr[:, 0]
+    x = np.ascontiguousarray(raw.transpose(0, 3, 1, 2).reshape(fields * 3, 10, 10, 1))
+    ain = np.ascontiguousarray(np.tile(lr, (fields, 1)))
+    aout = np.ascontiguousarray(np.tile(hr, (fields, 1)))
+    return x, ain, aout
+
+
+def tail_flops(n):
+    macs = 3 * 20_480_000 + 11_520_000  # ConvT#2..#4 + output conv
+    return 2.0 * macs * n
+
+
+def cpu_baseline(x, ain, aout, enc_w, dec_w, y_gpu_first, budget_s=12.0):
+    """Reference stand-in on the host cores: the oracle's torch-CPU (oneDNN, the
+    conv backend family TensorFlow uses) port of the network, Keras' default
+    predict batch of 32, plus numpy pre/post as the reference does them."""
+    import torch
+    from oracle.sr_oracle_torch import TorchSR
+    model = TorchSR(enc_w, dec_w, torch.float32)
+    bs = 32
+    xs = ((x[:bs] - ain[:bs, 0].reshape(-1, 1, 1, 1)) / ain[:bs, 1].reshape(-1, 1, 1, 1)).astype(np.float32)
+    y0 = model.forward(xs, batch_size=bs)  # warm-up (oneDNN primitive creation)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        lo = done % (len(x) - bs + 1)
+        xs = ((x[lo:lo + bs] - ain[lo:lo + bs, 0].reshape(-1, 1, 1, 1)) / ain[lo:lo + bs, 1].reshape(-1, 1, 1, 1)).astype(np.float32)
+        y = model.forward(xs, batch_size=bs)
+        y = y * aout[lo:lo + bs, 1].reshape(-1, 1, 1, 1) + aout[lo:lo + bs, 0].reshape(-1, 1, 1, 1)
+        if np.isnan(y).any() or np.isinf(y).any():
+            y = np.nan_to_num(y, nan=0.0, posinf=0.0, neginf=0.0)
+        done += bs
+        el = time.perf_counter() - t0
+        if el >= budget_s:
+            break
+    y0 = y0 * aout[:bs, 1].reshape(-1, 1, 1, 1) + aout[:bs, 0].reshape(-1, 1, 1, 1)
+    num = np.linalg.norm((y_gpu_first.astype(np.float64) - y0).reshape(bs, -1), axis=1)
+    den = np.linalg.norm(y0.reshape(bs, -1).astype(np.float64), axis=1)
+    return {
+        "value": round(done / 3.0 / el, 3), "unit": "fields/s", "cores": int(torch.get_num_threads()), "kind": "port",
+        "sample": f"{done} single-channel samples ({done // 3} fields) in batches of 32, f32, torch-CPU/oneDNN port of the network "
+                  f"(TensorFlow/Keras not installable; SURVEY.md 8c), {el:.1f} s",
+        "host_cpus": os.cpu_count(),
+        "gpu_vs_cpu_rel_l2_max": float(np.max(num / den)),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "fp32"])
+    ap.add_argument("--out-dtype", default="f32", choices=["f32", "bf16", "f16"])
+    ap.add_argument("--fields", type=int, default=FIELDS)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: libsrcfd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    srcfd = importlib.import_module("sr-for-cfd_amd")
+    synth = importlib.import_module("sr-for-cfd_amd.synth")
+    enc_w = srcfd.SRModel.load_h5(ENCODER_H5, None, device=-1).weights()   # real trained encoder (reference checkout)
+    dec_w = synth.synthetic_decoder_weights(1)                              # decoder .h5 absent upstream -> random init
+    model = srcfd.SRModel.from_weights(enc_w, dec_w, device=local_rank)
+    model.precision = args.precision
+    stats_lr, stats_hr = srcfd.load_stats(STATS_TXT, 10, 400)
+
+    x_h, ain_h, aout_h = build_inputs(args.fields, seed=rank, stats_lr=stats_lr, stats_hr=stats_hr)
+    n = x_h.shape[0]
+    x = torch.from_numpy(x_h).to(dev)
+    ain = torch.from_numpy(ain_h).to(dev)
+    aout = torch.from_numpy(aout_h).to(dev)
+    odt = {"f32": torch.float32, "bf16": torch.bfloat16, "f16": torch.float16}[args.out_dtype]
+    y = torch.empty((n, 400, 400, 1), dtype=odt, device=dev)
+    bad = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def step():
+        model.predict_device(x, y, in_affine=ain, out_affine=aout, nan_guard=True, nonfinite=bad)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+
+    # dominant-kernel timing with HIP events on the launch stream (rank 0)
+    roofline = None
+    kernels = {}
+    if rank == 0:
+        model.set_profiling(True)
+        reps = max(3, min(args.steps, 10))
+        acc = {}
+        for _ in range(reps):
+            step()
+            for name, ms in model.get_profile():
+                acc.setdefault(name, []).append(ms)
+        model.set_profiling(False)
+        kernels = {k: round(float(np.mean(v)), 4) for k, v in acc.items()}
+        if args.precision in ("bf16", "f16"):
+            dom = "tail(convT2-4+out)"
+            fl, peak = tail_flops(n), PEAK_BF16_TFLOPS
+        else:
+            dom = max(kernels, key=kernels.get)
+            fl, peak = None, PEAK_FP32_TFLOPS
+        if fl is not None:
+            ach = fl / (kernels[dom] * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(ach / peak, 4), "traffic": None, "avg_launch_ms": kernels[dom],
+                        "algorithmic_flops_per_launch": fl,
+                        "note": "swish needs 2 quarter-rate transcendentals per activation: VALU ceiling ~0.31 of MFMA peak (DESIGN.md)"}
+        else:
+            fl = 2.0 * MACS_PER_SAMPLE * n
+            tot = sum(kernels.values())
+            ach = fl / (tot * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": "all f32 kernels (sum)", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(ach / peak, 4), "traffic": None, "avg_launch_ms": round(tot, 4)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        y32 = torch.empty((32, 400, 400, 1), dtype=torch.float32, device=dev)
+        model.predict_device(x[:32].contiguous(), y32, in_affine=ain[:32].contiguous(), out_affine=aout[:32].contiguous(), nan_guard=True, nonfinite=bad)
+        torch.cuda.synchronize()
+        cpu = cpu_baseline(x_h, ain_h, aout_h, enc_w, dec_w, y32.cpu().numpy())
+
+    if rank == 0:
+        value = args.fields * world / (ms_per_step * 1e-3)
+        out = {
+            "metric": "SR fields/sec (10x10->400x400, 3-ch) @batch256", "value": round(value, 2), "unit": "fields/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: batched SR inference, 256 fields x (10,10,3)->(400,400,3) per GPU = 768 "
+                                   "single-channel encoder_10+decoder_400 passes, fused standardise/de-standardise/NaN guard",
+                       "fields_per_gpu": args.fields, "samples_per_gpu": n, "out_dtype": args.out_dtype,
+                       "weights": "encoder: reference multiBC .h5; decoder: random init seed 1 (reference decoder .h5 absent)",
+                       "parallelism": f"sample-sharded x{world}, no collective"},
+            "tflops_model": round(2.0 * MACS_PER_SAMPLE * n * world / (ms_per_step * 1e-3) / 1e12, 2),
+            "nonfinite": int(bad.item()),
+            "kernels_ms": kernels,
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -135,6 +135,11 @@ int srcfd_model_workspace(srcfd_model* m, int n, size_t* bytes);
  * '\n'-joined list; ms has one entry per name. */
 int srcfd_model_set_profiling(srcfd_model* m, int enable);
 int srcfd_model_get_profile(srcfd_model* m, char* names, size_t names_len, float* ms, int* count, int max_count);
+/* Test hook: copies the first `bytes` of inter-kernel activation buffer `index`
+ * (0 or 1) of the bf16/f16 pipeline to host memory after synchronising.  After a
+ * forward, buffer 0 holds ConvT#1's output (n,50,50,64) and buffer 1 ConvT#0's
+ * (n,25,25,128), both 16-bit and scaled by log2(e). */
+int srcfd_model_debug_activation(srcfd_model* m, int index, void* dst, size_t bytes);
 
 /* ---- stats file ----------------------------------------------------------
  * `key value` lines, '#' comments (PyCFD_ML_accelerated.py:787-797).  Looks up

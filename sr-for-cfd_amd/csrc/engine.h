@@ -72,6 +72,7 @@ struct Model {
 // bf16 / f16 fused path for the encoder_10 + decoder_400 graph.
 int fused_init(Model& m);
 void fused_free(Model& m);
+int fused_debug_read(Model& m, int index, void* dst, size_t bytes);
 int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, const float* aff_out, void* y_dev, int out_dtype,
                   int flags, unsigned long long* nonfinite, hipStream_t s);
 

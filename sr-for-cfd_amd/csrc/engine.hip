@@ -474,6 +474,11 @@ int srcfd_model_get_profile(srcfd_model* m, char* names, size_t names_len, float
   return SRCFD_OK;
 }
 
+int srcfd_model_debug_activation(srcfd_model* m, int index, void* dst, size_t bytes) {
+  if (!m || !dst || index < 0 || index > 1) { set_error("bad arguments"); return SRCFD_EINVAL; }
+  return srcfd::fused_debug_read(*M(m), index, dst, bytes);
+}
+
 int srcfd_model_save_h5(const srcfd_model* m, const char* encoder_h5, const char* decoder_h5) {
   if (!m) { set_error("null model"); return SRCFD_EINVAL; }
   const Model* mm = M(m);

@@ -1,10 +1,296 @@
-// bf16/f16 fused path -- placeholder until the kernels land.
+// Host side of the bf16 / f16 throughput path for the encoder_10 + decoder_400
+// graph: weight repacking (16-bit, log2e folding, MFMA fragment order) and the
+// eight-launch pipeline  conv1 -> conv2 -> dense -> latent -> dense_1 ->
+// ConvT#0 (4 phases) -> ConvT#1 -> fused tail.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
 #include "engine.h"
+#include "kernels16.h"
+
 namespace srcfd {
-int fused_init(Model&) { return SRCFD_OK; }
-void fused_free(Model&) {}
-int fused_forward(Model&, const float*, int, const float*, const float*, void*, int, int, unsigned long long*, hipStream_t) {
-  set_error("bf16/f16 fused path not built");
-  return SRCFD_EINVAL;
+
+#define HIPCHECK(expr)                                                               \
+  do {                                                                               \
+    hipError_t _e = (expr);                                                          \
+    if (_e != hipSuccess) {                                                          \
+      set_error(std::string(#expr) + " failed: " + hipGetErrorString(_e));           \
+      return SRCFD_EHIP;                                                             \
+    }                                                                                \
+  } while (0)
+
+static const double LOG2E = 1.4426950408889634;
+
+static uint16_t to_bf16(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                                           // round to nearest even
+  return (uint16_t)(u >> 16);
 }
+static uint16_t to_f16(float f) {
+  _Float16 hv = (_Float16)f;
+  uint16_t r;
+  std::memcpy(&r, &hv, 2);
+  return r;
+}
+static uint16_t to16(float f, bool f16) { return f16 ? to_f16(f) : to_bf16(f); }
+
+struct Op16 {
+  GemmDesc d;
+  size_t w_off = 0;  // elements into Pack16::d_w
+  size_t b_off = 0;  // floats into FusedState::d_f32
+  int Kpad = 0;
+  std::string name;
+  int layer = 0;
+};
+
+struct Pack16 {  // one per operand type (bf16, f16)
+  uint16_t* d_w = nullptr;
+  void* d_consts = nullptr;
+  void* d_w2f = nullptr;
+  bool built = false;
+};
+
+struct FusedState {
+  std::vector<int> cl;  // indices of the 11 compute layers in ModelDesc::layers
+  std::vector<Op16> ops;
+  std::vector<float> f32;  // conv1 weights [9][64], conv1 bias [64], per-op biases
+  size_t c1w_off = 0, c1b_off = 0;
+  float* d_f32 = nullptr;
+  Pack16 packs[2];
+  uint16_t* act[2] = {nullptr, nullptr};
+  int cap = 0;
+  int num_cus = 256;
+};
+
+static double scale_in(const ModelDesc& md, const std::vector<int>& cl, int i) {
+  return (i > 0 && md.layers[cl[i - 1]].act == SRCFD_ACT_SWISH) ? 1.0 / LOG2E : 1.0;
+}
+static double scale_out(const ModelDesc& md, const std::vector<int>& cl, int i) {
+  return md.layers[cl[i]].act == SRCFD_ACT_SWISH ? LOG2E : 1.0;
+}
+static double scale_w(const ModelDesc& md, const std::vector<int>& cl, int i) {
+  double si = scale_in(md, cl, i), so = scale_out(md, cl, i);
+  return (si != 1.0 && so != 1.0) ? 1.0 : si * so;  // swish -> swish: the factors cancel exactly
+}
+
+int fused_init(Model& m) {
+  FusedState* fs = new FusedState();
+  m.fused = fs;
+  const ModelDesc& md = m.desc;
+  for (size_t i = 0; i < md.layers.size(); ++i)
+    if (md.layers[i].kind != SRCFD_LAYER_FLATTEN && md.layers[i].kind != SRCFD_LAYER_RESHAPE) fs->cl.push_back((int)i);
+  hipDeviceProp_t prop;
+  HIPCHECK(hipGetDeviceProperties(&prop, m.device));
+  fs->num_cus = prop.multiProcessorCount;
+
+  // conv1 (VALU kernel): f32 weights, scaled
+  {
+    const Layer& L = md.layers[fs->cl[0]];
+    double sw = scale_w(md, fs->cl, 0), so = scale_out(md, fs->cl, 0);
+    fs->c1w_off = fs->f32.size();
+    for (float v : L.kernel) fs->f32.push_back((float)(v * sw));
+    fs->c1b_off = fs->f32.size();
+    for (float v : L.bias) fs->f32.push_back((float)(v * so));
+  }
+  // GEMM ops: compute layers 1..6 (conv2d_1, dense, latent_vector, dense_1, conv2d_transpose, conv2d_transpose_1)
+  for (const Op& op : m.ops) {
+    int ci = -1;
+    for (size_t k = 0; k < fs->cl.size(); ++k) if (fs->cl[k] == op.layer) ci = (int)k;
+    if (ci < 1 || ci > 6) continue;
+    Op16 o;
+    o.d = op.d;
+    o.name = op.name;
+    o.layer = ci;
+    if (ci == 3) { o.d.N = 64; o.d.CO = 64; o.d.OC = 64; }   // latent 50 -> 64 zero-padded channels
+    if (ci == 4) { o.d.CI = 64; o.d.K = 64; }                // dense_1 reads the padded latent
+    o.d.Npad = (o.d.N + 63) / 64 * 64;
+    o.Kpad = (o.d.K + 31) / 32 * 32;
+    if (o.d.CI % 32 != 0 || o.d.K % 32 != 0 || o.d.N % 4 != 0 || o.d.CO % 4 != 0) { set_error("fused path: unsupported channel count in " + op.name); return SRCFD_EINVAL; }
+    const double so = scale_out(md, fs->cl, ci);
+    while (fs->f32.size() % 4) fs->f32.push_back(0.f);
+    o.b_off = fs->f32.size();
+    for (int n = 0; n < o.d.Npad; ++n) fs->f32.push_back(n < op.d.N ? (float)(m.pack[op.b_off + n] * so) : 0.f);
+    fs->ops.push_back(o);
+  }
+  if (fs->ops.size() != 9) { set_error("fused path: unexpected plan shape"); return SRCFD_EINVAL; }
+  HIPCHECK(hipMalloc(&fs->d_f32, fs->f32.size() * sizeof(float)));
+  HIPCHECK(hipMemcpy(fs->d_f32, fs->f32.data(), fs->f32.size() * sizeof(float), hipMemcpyHostToDevice));
+  return SRCFD_OK;
+}
+
+static int build_pack(Model& m, FusedState* fs, bool f16) {
+  Pack16& P = fs->packs[f16 ? 1 : 0];
+  if (P.built) return SRCFD_OK;
+  const ModelDesc& md = m.desc;
+  // ---- GEMM weights, transposed: Wt[Npad][Kpad] ----
+  std::vector<uint16_t> w;
+  size_t oi = 0;
+  for (const Op& op : m.ops) {
+    int ci = -1;
+    for (size_t k = 0; k < fs->cl.size(); ++k) if (fs->cl[k] == op.layer) ci = (int)k;
+    if (ci < 1 || ci > 6) continue;
+    Op16& o = fs->ops[oi++];
+    const double sw = scale_w(md, fs->cl, ci);
+    while (w.size() % 8) w.push_back(0);
+    o.w_off = w.size();
+    w.resize(w.size() + (size_t)o.d.Npad * o.Kpad, 0);
+    for (int n = 0; n < op.d.N; ++n)
+      for (int k = 0; k < op.d.K; ++k)
+        w[o.w_off + (size_t)n * o.Kpad + k] = to16((float)(m.pack[op.w_off + (size_t)k * op.d.Npad + n] * sw), f16);
+  }
+  HIPCHECK(hipMalloc(&P.d_w, w.size() * sizeof(uint16_t)));
+  HIPCHECK(hipMemcpy(P.d_w, w.data(), w.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+
+  // ---- tail constants ----
+  const Layer& L2 = md.layers[fs->cl[7]];   // ConvT 64->32, kernel (2,2,32,64)
+  const Layer& L3 = md.layers[fs->cl[8]];   // ConvT 32->16, kernel (2,2,16,32)
+  const Layer& L4 = md.layers[fs->cl[9]];   // ConvT 16->8,  kernel (2,2,8,16)
+  const Layer& LO = md.layers[fs->cl[10]];  // Conv 8->1,    kernel (3,3,8,1)
+  auto rowof = [](int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; };  // 32x32 accumulator row of register r
+  std::vector<uint8_t> cst(TAIL_CONST_BYTES, 0);
+  uint16_t* wc = reinterpret_cast<uint16_t*>(cst.data() + TC_OFF_WC);
+  for (int kk = 0; kk < 10; ++kk)
+    for (int l = 0; l < 64; ++l) {
+      int n = l & 15, kg = l >> 4, oy = n >> 3, ox = n & 7;
+      int wy = 2 * (kk / 5) + (kg & 1), wx = 2 * (kk % 5) + (kg >> 1);
+      int ky = wy - oy, kx = wx - ox;
+      for (int c = 0; c < 8; ++c) {
+        float v = 0.f;
+        if (ky >= 0 && ky < 3 && kx >= 0 && kx < 3) v = (float)(LO.kernel[(size_t)(ky * 3 + kx) * 8 + c] / LOG2E);
+        wc[((size_t)kk * 64 + l) * 8 + c] = to16(v, f16);
+      }
+    }
+  uint16_t* w3 = reinterpret_cast<uint16_t*>(cst.data() + TC_OFF_W3);
+  for (int m3 = 0; m3 < 2; ++m3)
+    for (int kk = 0; kk < 2; ++kk)
+      for (int l = 0; l < 64; ++l) {
+        int i = l & 31, hh = l >> 5, tap = 2 * m3 + (i >> 4), co = i & 15;
+        for (int j = 0; j < 8; ++j) {
+          int ci = 16 * kk + 8 * hh + j;
+          w3[(((size_t)m3 * 2 + kk) * 64 + l) * 8 + j] = to16(L3.kernel[((size_t)tap * 16 + co) * 32 + ci], f16);
+        }
+      }
+  uint16_t* w4 = reinterpret_cast<uint16_t*>(cst.data() + TC_OFF_W4);
+  for (int l = 0; l < 64; ++l) {
+    int i = l & 31, hh = l >> 5, tap = i >> 3, co = i & 7;
+    for (int j = 0; j < 8; ++j) {
+      int ci = (j & 3) + 8 * (j >> 2) + 4 * hh;  // k order of an accumulator used as the next B operand
+      w4[(size_t)l * 8 + j] = to16(L4.kernel[((size_t)tap * 8 + co) * 16 + ci], f16);
+    }
+  }
+  float* b2 = reinterpret_cast<float*>(cst.data() + TC_OFF_B2);
+  float* b3 = reinterpret_cast<float*>(cst.data() + TC_OFF_B3);
+  float* b4 = reinterpret_cast<float*>(cst.data() + TC_OFF_B4);
+  for (int hh = 0; hh < 2; ++hh)
+    for (int r = 0; r < 16; ++r) {
+      int row = rowof(r, hh);
+      b2[hh * 16 + r] = (float)(L2.bias[row] * LOG2E);
+      b3[hh * 16 + r] = (float)(L3.bias[row & 15] * LOG2E);
+      b4[hh * 16 + r] = (float)(L4.bias[row & 7] * LOG2E);
+    }
+  *reinterpret_cast<float*>(cst.data() + TC_OFF_BC) = LO.bias[0];
+  HIPCHECK(hipMalloc(&P.d_consts, cst.size()));
+  HIPCHECK(hipMemcpy(P.d_consts, cst.data(), cst.size(), hipMemcpyHostToDevice));
+
+  std::vector<uint16_t> w2((size_t)4 * 4 * 64 * 8);
+  for (int mt = 0; mt < 4; ++mt)
+    for (int kk = 0; kk < 4; ++kk)
+      for (int l = 0; l < 64; ++l) {
+        int co = l & 31, hh = l >> 5;
+        for (int j = 0; j < 8; ++j) {
+          int ci = 16 * kk + 8 * hh + j;
+          w2[(((size_t)mt * 4 + kk) * 64 + l) * 8 + j] = to16(L2.kernel[((size_t)mt * 32 + co) * 64 + ci], f16);
+        }
+      }
+  HIPCHECK(hipMalloc(&P.d_w2f, w2.size() * sizeof(uint16_t)));
+  HIPCHECK(hipMemcpy(P.d_w2f, w2.data(), w2.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  P.built = true;
+  return SRCFD_OK;
+}
+
+void fused_free(Model& m) {
+  FusedState* fs = m.fused;
+  if (!fs) return;
+  for (auto& P : fs->packs) {
+    if (P.d_w) (void)hipFree(P.d_w);
+    if (P.d_consts) (void)hipFree(P.d_consts);
+    if (P.d_w2f) (void)hipFree(P.d_w2f);
+  }
+  if (fs->d_f32) (void)hipFree(fs->d_f32);
+  for (auto* b : fs->act) if (b) (void)hipFree(b);
+  delete fs;
+  m.fused = nullptr;
+}
+
+int fused_debug_read(Model& m, int index, void* dst, size_t bytes) {
+  FusedState* fs = m.fused;
+  if (!fs || !fs->act[index]) { set_error("no fused activations yet"); return SRCFD_EINVAL; }
+  if (bytes > (size_t)fs->cap * 160000 * sizeof(uint16_t)) { set_error("read past the activation buffer"); return SRCFD_EINVAL; }
+  HIPCHECK(hipSetDevice(m.device));
+  HIPCHECK(hipDeviceSynchronize());
+  HIPCHECK(hipMemcpy(dst, fs->act[index], bytes, hipMemcpyDeviceToHost));
+  return SRCFD_OK;
+}
+
+static const size_t ACT_ELEMS = 160000;  // largest inter-kernel activation per sample: (50,50,64)
+
+int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, const float* aff_out, void* y_dev, int out_dtype, int flags,
+                  unsigned long long* nonfinite, hipStream_t s) {
+  FusedState* fs = m.fused;
+  if (!fs) { set_error("fused path not initialised"); return SRCFD_EINVAL; }
+  const bool f16 = m.precision == SRCFD_PREC_F16;
+  int rc = build_pack(m, fs, f16);
+  if (rc) return rc;
+  const Pack16& P = fs->packs[f16 ? 1 : 0];
+  const int want = std::min(n, 1024);
+  if (want > fs->cap) {
+    for (auto*& b : fs->act) if (b) { HIPCHECK(hipFree(b)); b = nullptr; }
+    fs->cap = 0;
+    for (auto*& b : fs->act) HIPCHECK(hipMalloc(&b, (size_t)want * ACT_ELEMS * sizeof(uint16_t)));
+    fs->cap = want;
+  }
+  const size_t osz = out_dtype == SRCFD_F32 ? 4 : 2;
+  for (int i0 = 0; i0 < n; i0 += fs->cap) {
+    const int c = std::min(fs->cap, n - i0);
+    const float* xin = x_dev + (size_t)i0 * 100;
+    const float* ain = aff_in ? aff_in + 2 * (size_t)i0 : nullptr;
+    const float* aout = aff_out ? aff_out + 2 * (size_t)i0 : nullptr;
+    int cur = 0;
+    rc = m.launch("conv2d", s, [&] { return launch_enc_conv1_16(f16, xin, ain, fs->d_f32 + fs->c1w_off, fs->d_f32 + fs->c1b_off, fs->act[0], c, s); });
+    if (rc) return rc;
+    int prev_layer = -1;
+    for (const Op16& o : fs->ops) {
+      if (o.layer != prev_layer && prev_layer >= 0) cur ^= 1;
+      prev_layer = o.layer;
+      GemmDesc d = o.d;
+      d.M = c * d.MH * d.MW;
+      const uint16_t* X = fs->act[cur];
+      uint16_t* Y = fs->act[cur ^ 1];
+      rc = m.launch(o.name.c_str(), s, [&] { return launch_gemm16(f16, d, X, P.d_w + o.w_off, o.Kpad, fs->d_f32 + o.b_off, Y, s); });
+      if (rc) return rc;
+    }
+    cur ^= 1;
+    TailParams tp;
+    tp.in = fs->act[cur];
+    tp.out = (char*)y_dev + (size_t)i0 * 160000 * osz;
+    tp.n = c;
+    tp.consts = P.d_consts;
+    tp.w2frags = P.d_w2f;
+    tp.aff_out = aout;
+    tp.nan_guard = flags & SRCFD_FLAG_NAN_GUARD;
+    tp.nonfinite = nonfinite;
+    tp.out_dtype = out_dtype;
+    const int blocks = std::min(c, fs->num_cus);
+    rc = m.launch("tail(convT2-4+out)", s, [&] { return launch_tail16(f16, tp, blocks, s); });
+    if (rc) return rc;
+  }
+  return SRCFD_OK;
+}
+
 }  // namespace srcfd

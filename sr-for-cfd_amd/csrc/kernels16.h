@@ -1,0 +1,38 @@
+// Declarations shared by kernels_bf16.hip (device) and fused_bf16.hip (host).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels.h"
+
+namespace srcfd {
+
+// Constant blob the tail kernel copies into LDS (byte offsets).  Fragment
+// arrays hold one 16-byte MFMA operand per lane: [fragment][64 lanes].
+constexpr int TC_OFF_WC = 0;                      // output-conv Toeplitz B operands, 10 k-steps (16x16x32)
+constexpr int TC_OFF_W3 = TC_OFF_WC + 10 * 1024;  // ConvT#3 A operands [m-tile 2][k-step 2]
+constexpr int TC_OFF_W4 = TC_OFF_W3 + 4 * 1024;   // ConvT#4 A operand (k permuted to accumulator order)
+constexpr int TC_OFF_B2 = TC_OFF_W4 + 1024;       // bias as 32x32 accumulator init, [lane half 2][16] f32
+constexpr int TC_OFF_B3 = TC_OFF_B2 + 128;
+constexpr int TC_OFF_B4 = TC_OFF_B3 + 128;
+constexpr int TC_OFF_BC = TC_OFF_B4 + 128;        // output-conv bias (f32) + padding
+constexpr int TAIL_CONST_BYTES = TC_OFF_BC + 16;
+
+struct TailParams {
+  const uint16_t* in;      // (n,50,50,64) activations of ConvT#1, scaled by log2e
+  void* out;               // (n,400,400) of out_dtype
+  int n;
+  const void* consts;      // TAIL_CONST_BYTES, device
+  const void* w2frags;     // ConvT#2 A operands [m-tile 4][k-step 4][64 lanes] x 16 B, device
+  const float* aff_out;    // (n,2) mean,std or null
+  int nan_guard;
+  unsigned long long* nonfinite;
+  int out_dtype;
+};
+
+hipError_t launch_enc_conv1_16(bool f16, const float* x, const float* affine, const float* w, const float* b, uint16_t* y, int n, hipStream_t s);
+hipError_t launch_gemm16(bool f16, const GemmDesc& d, const uint16_t* X, const uint16_t* Wt, int Kpad, const float* bias, uint16_t* Y, hipStream_t s);
+hipError_t launch_tail16(bool f16, const TailParams& p, int blocks, hipStream_t s);
+int tail_lds_bytes();
+
+}  // namespace srcfd

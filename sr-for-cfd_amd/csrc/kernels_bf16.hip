@@ -1,0 +1,404 @@
+// bf16 / f16 kernels of the SR engine (gfx950 only): the throughput path.
+//
+//   enc_conv1_16   Conv2D 3x3 s2 SAME 1->64 + standardise + swish (VALU)        SURVEY 8a rows a2, a7
+//   gemm16         implicit GEMM on v_mfma_f32_32x32x16_{bf16,f16}; same GemmDesc
+//                  as the f32 engine; pixels on the MFMA column (lane) axis so a
+//                  lane owns 4 consecutive output channels -> 8-byte stores     rows a8-a14
+//   tail16         ConvT#2 -> ConvT#3 -> ConvT#4 -> output conv + de-standardise
+//                  + NaN guard, one launch, nothing between 50x50x64 and the
+//                  400x400 image touches HBM                                     rows a15-a20
+//
+// Activations carry a factor log2(e): every swish layer's GEMM produces
+// u = log2e * x, the epilogue computes u * rcp(1 + exp2(-u)) = log2e * swish(x)
+// (v_exp_f32 with a negated source, no extra multiply) and the consumer's
+// weights absorb 1/log2e on the host.  For swish->swish layers the two factors
+// cancel and the weights are used as they are.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kernels16.h"
+
+namespace srcfd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma32(const uint4& a, const uint4& b, const f32x16& c) {
+  if (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b), c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, const f32x4& c) {
+  if (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b), c, 0, 0, 0);
+}
+
+template <bool F16>
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  f32x2 v = {lo, hi};
+  if (F16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, h16x2));
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));  // v_cvt_pk_bf16_f32, RNE
+}
+
+// u = log2e * x  ->  log2e * swish(x)
+__device__ __forceinline__ float swish_scaled(float u) {
+  float e = __builtin_amdgcn_exp2f(-u);
+  return u * __builtin_amdgcn_rcpf(1.0f + e);
+}
+__device__ __forceinline__ float act16(float u, int act) { return act == SRCFD_ACT_SWISH ? swish_scaled(u) : u; }
+
+// ---------------------------------------------------------------------------
+// encoder conv #1: x (n,10,10,1) f32 [+ standardise] -> (n,5,5,64) bf16/f16
+// one thread = 4 output channels of one output pixel
+// ---------------------------------------------------------------------------
+template <bool F16>
+__global__ void __launch_bounds__(256) enc_conv1_16(const float* __restrict__ x, const float* __restrict__ affine,
+                                                     const float* __restrict__ w /*[9][64] scaled*/, const float* __restrict__ b /*[64] scaled*/,
+                                                     uint16_t* __restrict__ y, int n) {
+  int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n * 25 * 16) return;
+  int c4 = idx & 15, pix = (idx >> 4) % 25, s = idx / (25 * 16);
+  int oy = pix / 5, ox = pix - oy * 5;
+  float mean = 0.f, sd = 1.f;
+  if (affine) { mean = affine[2 * s]; sd = affine[2 * s + 1]; if (sd == 0.f) sd = 1e-8f; }
+  float acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c] = b[c4 * 4 + c];
+  const float* xs = x + (size_t)s * 100;
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    int iy = 2 * oy + ky;  // TF SAME, stride 2, 10->5: pad 0 before / 1 after
+    if (iy >= 10) continue;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      int ix = 2 * ox + kx;
+      if (ix >= 10) continue;
+      float v = xs[iy * 10 + ix];
+      if (affine) v = __fdiv_rn(__fsub_rn(v, mean), sd);
+      const float* wp = w + (ky * 3 + kx) * 64 + c4 * 4;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[c] = fmaf(v, wp[c], acc[c]);
+    }
+  }
+  uint2 o;
+  o.x = pack2<F16>(swish_scaled(acc[0]), swish_scaled(acc[1]));
+  o.y = pack2<F16>(swish_scaled(acc[2]), swish_scaled(acc[3]));
+  *reinterpret_cast<uint2*>(y + ((size_t)s * 25 + pix) * 64 + c4 * 4) = o;
+}
+
+// ---------------------------------------------------------------------------
+// implicit GEMM, 16-bit operands.  D[channel][pixel] = Wt[channel][k] * X[pixel][k]
+// Block 256 threads; tile 128 pixels x BN channels x 32 k.
+// ---------------------------------------------------------------------------
+constexpr int G_BP = 128, G_BK = 32, G_PITCH = 40;  // LDS row pitch in elements (80 B: conflict-free b128 reads)
+
+template <bool F16, int BN>
+__global__ void __launch_bounds__(256) gemm16(GemmDesc d, const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wt, int Kpad,
+                                               const float* __restrict__ bias, uint16_t* __restrict__ Y) {
+  constexpr int PT = BN == 128 ? 2 : 1;  // 32-pixel tiles per wave
+  __shared__ __attribute__((aligned(16))) uint16_t Xs[G_BP * G_PITCH];
+  __shared__ __attribute__((aligned(16))) uint16_t Ws[BN * G_PITCH];
+  __shared__ int row_img[G_BP], row_my[G_BP], row_mx[G_BP];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+  const int wc = BN == 128 ? (wave >> 1) : 0, wp = BN == 128 ? (wave & 1) : wave;
+  const int m0 = blockIdx.x * G_BP, n0 = blockIdx.y * BN;
+
+  if (tid < G_BP) {
+    int m = m0 + tid, img = -1, my = 0, mx = 0;
+    if (m < d.M) {
+      int per = d.MH * d.MW;
+      img = m / per;
+      int r = m - img * per;
+      my = r / d.MW;
+      mx = r - my * d.MW;
+    }
+    row_img[tid] = img; row_my[tid] = my; row_mx[tid] = mx;
+  }
+  __syncthreads();
+
+  f32x16 acc[2][PT];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < PT; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  for (int k0 = 0; k0 < d.K; k0 += G_BK) {
+    int tap = k0 / d.CI, ci0 = k0 - tap * d.CI;
+    int ty = tap / d.TX, tx = tap - ty * d.TX;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      int c = tid + 256 * j, row = c >> 2, c4 = c & 3;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      int img = row_img[row];
+      if (img >= 0) {
+        int iy = row_my[row] * d.ay + ty * d.by + d.cy, ix = row_mx[row] * d.ax + tx * d.bx + d.cx;
+        if (iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW)
+          v = *reinterpret_cast<const uint4*>(X + (((int64_t)img * d.IH + iy) * d.IW + ix) * d.CI + ci0 + c4 * 8);
+      }
+      *reinterpret_cast<uint4*>(Xs + row * G_PITCH + c4 * 8) = v;
+    }
+#pragma unroll
+    for (int j = 0; j < BN / 64; ++j) {
+      int c = tid + 256 * j, row = c >> 2, c4 = c & 3;
+      uint4 v = *reinterpret_cast<const uint4*>(Wt + (int64_t)(n0 + row) * Kpad + k0 + c4 * 8);
+      *reinterpret_cast<uint4*>(Ws + row * G_PITCH + c4 * 8) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      uint4 af[2], bf[PT];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) af[a] = *reinterpret_cast<const uint4*>(Ws + (wc * 64 + a * 32 + l31) * G_PITCH + kk * 16 + h * 8);
+#pragma unroll
+      for (int b = 0; b < PT; ++b) bf[b] = *reinterpret_cast<const uint4*>(Xs + (wp * 32 * PT + b * 32 + l31) * G_PITCH + kk * 16 + h * 8);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < PT; ++b) acc[a][b] = mfma32<F16>(af[a], bf[b], acc[a][b]);
+    }
+    __syncthreads();
+  }
+
+  // epilogue: lane = pixel, 4 consecutive channels per register quad
+#pragma unroll
+  for (int b = 0; b < PT; ++b) {
+    int prow = wp * 32 * PT + b * 32 + l31;
+    int img = row_img[prow];
+    if (img < 0) continue;
+    int my = row_my[prow], mx = row_mx[prow];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        int n = n0 + wc * 64 + a * 32 + 8 * q + 4 * h;
+        if (n >= d.N) continue;
+        int ph = n / d.CO, co = n - ph * d.CO;
+        int py = ph / d.nphx, px = ph - py * d.nphx;
+        int oy = my * d.os + d.oy0 + py, ox = mx * d.os + d.ox0 + px;
+        float4 bv = *reinterpret_cast<const float4*>(bias + n);
+        float v0 = act16(acc[a][b][4 * q + 0] + bv.x, d.act), v1 = act16(acc[a][b][4 * q + 1] + bv.y, d.act);
+        float v2 = act16(acc[a][b][4 * q + 2] + bv.z, d.act), v3 = act16(acc[a][b][4 * q + 3] + bv.w, d.act);
+        uint2 o;
+        o.x = pack2<F16>(v0, v1);
+        o.y = pack2<F16>(v2, v3);
+        *reinterpret_cast<uint2*>(Y + (((int64_t)img * d.OH + oy) * d.OW + ox) * d.OC + co) = o;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// fused tail.  One 1024-thread workgroup per CU walks a sample top to bottom
+// in strips of one 50x50-level row (= 2 rows at 100x100, 8 rows at 400x400).
+// Every round the 16 waves pull work items from an LDS counter:
+//   BC(s): 32 pixels of the 100x100 level -> ConvT#3 -> ConvT#4 in registers
+//          (the f32 accumulator of one MFMA is the B operand of the next),
+//          swish in the epilogues, 400x400x8 rows written to an 18-row LDS ring
+//   A(s+1): ConvT#2 for the next strip, global 50x50x64 -> LDS 100x100x32
+//   D(s-1): output 3x3 conv of the previous strip as a banded (Toeplitz) MFMA
+//          over 2x8-pixel tiles read from the ring, + de-standardise + guard
+// ---------------------------------------------------------------------------
+constexpr int T_RING_ROWS = 18, T_ROWP = 400 * 16;
+constexpr int T_OFF_RING = 0;
+constexpr int T_OFF_L100 = T_RING_ROWS * T_ROWP;            // 115200
+constexpr int T_L100_ROW = 100 * 64, T_L100_BUF = 2 * T_L100_ROW;
+constexpr int T_OFF_CONST = T_OFF_L100 + 2 * T_L100_BUF;    // 140800: blob copied from TailParams::consts
+constexpr int T_OFF_CTR = T_OFF_CONST + TAIL_CONST_BYTES;
+constexpr int T_LDS_BYTES = T_OFF_CTR + 16;
+
+template <bool F16>
+__device__ __forceinline__ void swish_pack16(const f32x16& dd, uint32_t (&o)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = pack2<F16>(swish_scaled(dd[2 * i]), swish_scaled(dd[2 * i + 1]));
+}
+
+__device__ __forceinline__ f32x16 load_bias16(const char* base) {
+  f32x16 r;
+  const float4* p = reinterpret_cast<const float4*>(base);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { float4 v = p[i]; r[4 * i] = v.x; r[4 * i + 1] = v.y; r[4 * i + 2] = v.z; r[4 * i + 3] = v.w; }
+  return r;
+}
+
+template <bool F16, int OUT>  // OUT: 0 f32, 1 bf16, 2 f16
+__global__ void __launch_bounds__(1024) tail16(TailParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
+  char* ring = smem + T_OFF_RING;
+  char* l100 = smem + T_OFF_L100;
+  const char* cst = smem + T_OFF_CONST;
+  int* ctr = reinterpret_cast<int*>(smem + T_OFF_CTR);
+
+  for (int i = tid; i < TAIL_CONST_BYTES / 16; i += 1024)
+    reinterpret_cast<uint4*>(smem + T_OFF_CONST)[i] = reinterpret_cast<const uint4*>(p.consts)[i];
+  if (tid < 2) ctr[tid] = 0;
+  __syncthreads();
+
+  const uint4* wc_f = reinterpret_cast<const uint4*>(cst + TC_OFF_WC);
+  const uint4* w3_f = reinterpret_cast<const uint4*>(cst + TC_OFF_W3);
+  const uint4* w4_f = reinterpret_cast<const uint4*>(cst + TC_OFF_W4);
+  const uint4* w2_f = reinterpret_cast<const uint4*>(p.w2frags);
+  const float conv_bias = *reinterpret_cast<const float*>(cst + TC_OFF_BC);
+
+  int round = 0;
+  for (int sample = blockIdx.x; sample < p.n; sample += gridDim.x) {
+    const uint16_t* in_s = p.in + (size_t)sample * 50 * 50 * 64;
+    float o_mean = 0.f, o_std = 1.f;
+    if (p.aff_out) { o_mean = p.aff_out[2 * sample]; o_std = p.aff_out[2 * sample + 1]; }
+    unsigned bad_count = 0;
+
+    for (int rho = 0; rho <= 52; ++rho, ++round) {
+      const int nBC = (rho >= 1 && rho <= 50) ? 14 : 0, nA = (rho <= 49) ? 8 : 0, nD = (rho >= 2) ? 13 : 0;
+      const int total = nBC + nA + nD;
+      if (tid == 0) ctr[(round + 1) & 1] = 0;
+      for (;;) {
+        int it = 0;
+        if (lane == 0) it = atomicAdd(&ctr[round & 1], 1);
+        it = __builtin_amdgcn_readfirstlane(it);
+        if (it >= total) break;
+
+        if (it < nBC) {
+          // ---------------- BC: ConvT#3 + ConvT#4 on 32 pixels of the 100-level ----------------
+          const int s = rho - 1, t = it >> 1, m3 = it & 1;
+          int idx = 32 * t + l31;
+          const bool valid = idx < 200;
+          if (!valid) idx = 199;
+          const int a = idx >= 100 ? 1 : 0, x100 = idx - 100 * a;
+          const char* src = l100 + (s & 1) * T_L100_BUF + (a * 100 + x100) * 64 + 16 * h;
+          uint4 b0 = *reinterpret_cast<const uint4*>(src), b1 = *reinterpret_cast<const uint4*>(src + 32);
+          f32x16 acc3 = load_bias16(cst + TC_OFF_B3 + h * 64);
+          acc3 = mfma32<F16>(w3_f[(m3 * 2 + 0) * 64 + lane], b0, acc3);
+          acc3 = mfma32<F16>(w3_f[(m3 * 2 + 1) * 64 + lane], b1, acc3);
+          uint32_t f3[8];
+          swish_pack16<F16>(acc3, f3);
+          const uint4 w4 = w4_f[lane];
+          const f32x16 bias4 = load_bias16(cst + TC_OFF_B4 + h * 64);
+#pragma unroll
+          for (int tt = 0; tt < 2; ++tt) {
+            const int tap3 = 2 * m3 + tt, a3 = tap3 >> 1, b3 = tap3 & 1;
+            uint4 bf = make_uint4(f3[4 * tt], f3[4 * tt + 1], f3[4 * tt + 2], f3[4 * tt + 3]);
+            f32x16 acc4 = mfma32<F16>(w4, bf, bias4);
+            uint32_t f4[8];
+            swish_pack16<F16>(acc4, f4);
+            if (valid) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const int Y = 8 * s + 4 * a + 2 * a3 + (q >> 1), X = 4 * x100 + 2 * b3 + (q & 1);
+                *reinterpret_cast<uint2*>(ring + (Y % T_RING_ROWS) * T_ROWP + X * 16 + 8 * h) = make_uint2(f4[2 * q], f4[2 * q + 1]);
+              }
+            }
+          }
+        } else if (it < nBC + nA) {
+          // ---------------- A: ConvT#2 for strip rho, global -> LDS ----------------
+          const int s = rho, item = it - nBC, mt = item & 3, ct = item >> 2;
+          const int px = 32 * ct + l31;
+          const bool valid = px < 50;
+          const uint16_t* src = in_s + ((size_t)s * 50 + (valid ? px : 49)) * 64 + 8 * h;
+          f32x16 acc = load_bias16(cst + TC_OFF_B2 + h * 64);
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            uint4 b = *reinterpret_cast<const uint4*>(src + 16 * kk);
+            acc = mfma32<F16>(w2_f[(mt * 4 + kk) * 64 + lane], b, acc);
+          }
+          uint32_t f2[8];
+          swish_pack16<F16>(acc, f2);
+          if (valid) {
+            const int a = mt >> 1, x100 = 2 * px + (mt & 1);
+            char* dst = l100 + (s & 1) * T_L100_BUF + (a * 100 + x100) * 64 + 8 * h;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(dst + 16 * q) = make_uint2(f2[2 * q], f2[2 * q + 1]);
+          }
+        } else {
+          // ---------------- D: output conv of strip rho-2, rows 8s-1 .. 8s+6 ----------------
+          const int s = rho - 2, j = it - nBC - nA;
+          const int m = lane & 15, kg = lane >> 4;
+          int T = 16 * j + 4 * (m & 3) + (m >> 2);
+          if (T > 199) T = 199;
+          const int rp = T / 50, tx = T - 50 * rp;
+          const int Yt = 8 * s - 1 + 2 * rp;  // first output row of the tile
+          f32x4 acc = {conv_bias, conv_bias, conv_bias, conv_bias};
+#pragma unroll
+          for (int kk = 0; kk < 10; ++kk) {
+            const int wy = 2 * (kk / 5) + (kg & 1), wx = 2 * (kk % 5) + (kg >> 1);
+            const int Yw = Yt - 1 + wy, Xw = 8 * tx - 1 + wx;
+            const bool ok = Yw >= 0 && Yw < 400 && Xw >= 0 && Xw < 400;
+            uint4 av = make_uint4(0, 0, 0, 0);
+            if (ok) av = *reinterpret_cast<const uint4*>(ring + (Yw % T_RING_ROWS) * T_ROWP + Xw * 16);
+            acc = mfma16<F16>(av, wc_f[kk * 64 + lane], acc);
+          }
+          const int oy = m >> 3, ox = m & 7;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int To = 16 * j + 4 * r + kg;
+            if (To > 199) continue;
+            const int rpo = To / 50, txo = To - 50 * rpo;
+            const int Y = 8 * s - 1 + 2 * rpo + oy, X = 8 * txo + ox;
+            if (Y < 0 || Y >= 400) continue;
+            float v = acc[r];
+            if (p.aff_out) v = __fadd_rn(__fmul_rn(v, o_std), o_mean);
+            if (p.nan_guard && !(fabsf(v) <= 3.402823466e38f)) { v = 0.f; ++bad_count; }
+            const size_t o = ((size_t)sample * 400 + Y) * 400 + X;
+            if (OUT == 0) reinterpret_cast<float*>(p.out)[o] = v;
+            else if (OUT == 1) reinterpret_cast<uint16_t*>(p.out)[o] = (uint16_t)(pack2<false>(v, 0.f) & 0xffff);
+            else reinterpret_cast<uint16_t*>(p.out)[o] = (uint16_t)(pack2<true>(v, 0.f) & 0xffff);
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (p.nan_guard && p.nonfinite && bad_count) atomicAdd(p.nonfinite, (unsigned long long)bad_count);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+hipError_t launch_enc_conv1_16(bool f16, const float* x, const float* affine, const float* w, const float* b, uint16_t* y, int n, hipStream_t s) {
+  if (n == 0) return hipSuccess;
+  dim3 grid((n * 25 * 16 + 255) / 256);
+  if (f16) hipLaunchKernelGGL(enc_conv1_16<true>, grid, dim3(256), 0, s, x, affine, w, b, y, n);
+  else hipLaunchKernelGGL(enc_conv1_16<false>, grid, dim3(256), 0, s, x, affine, w, b, y, n);
+  return hipGetLastError();
+}
+
+hipError_t launch_gemm16(bool f16, const GemmDesc& d, const uint16_t* X, const uint16_t* Wt, int Kpad, const float* bias, uint16_t* Y, hipStream_t s) {
+  if (d.M == 0) return hipSuccess;
+  const bool wide = d.Npad % 128 == 0;
+  dim3 grid((d.M + G_BP - 1) / G_BP, d.Npad / (wide ? 128 : 64));
+#define GO(F, B) hipLaunchKernelGGL((gemm16<F, B>), grid, dim3(256), 0, s, d, X, Wt, Kpad, bias, Y)
+  if (f16) { if (wide) GO(true, 128); else GO(true, 64); }
+  else { if (wide) GO(false, 128); else GO(false, 64); }
+#undef GO
+  return hipGetLastError();
+}
+
+int tail_lds_bytes() { return T_LDS_BYTES; }
+
+hipError_t launch_tail16(bool f16, const TailParams& p, int blocks, hipStream_t s) {
+  if (p.n == 0) return hipSuccess;
+  static bool attr_done[2][3] = {};
+  void (*fn)(TailParams) = nullptr;
+#define PICK(F, O) fn = tail16<F, O>
+  if (f16) { if (p.out_dtype == SRCFD_F32) PICK(true, 0); else if (p.out_dtype == SRCFD_BF16) PICK(true, 1); else PICK(true, 2); }
+  else { if (p.out_dtype == SRCFD_F32) PICK(false, 0); else if (p.out_dtype == SRCFD_BF16) PICK(false, 1); else PICK(false, 2); }
+#undef PICK
+  int oi = p.out_dtype == SRCFD_F32 ? 0 : (p.out_dtype == SRCFD_BF16 ? 1 : 2);
+  if (!attr_done[f16 ? 1 : 0][oi]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
+    if (e != hipSuccess) return e;
+    attr_done[f16 ? 1 : 0][oi] = true;
+  }
+  hipLaunchKernelGGL(fn, dim3(blocks), dim3(1024), T_LDS_BYTES, s, p);
+  return hipGetLastError();
+}
+
+}  // namespace srcfd

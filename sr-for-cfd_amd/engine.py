@@ -234,6 +234,12 @@ class SRModel:
         L.check(L.lib.srcfd_predict_device(self._h, p(x), n, p(in_affine), p(out_affine), p(y), dt,
                                            L.FLAG_NAN_GUARD if nan_guard else 0, p(nonfinite), C.c_void_p(st.cuda_stream)))
 
+    def debug_activation(self, index: int, shape, dtype=np.uint16) -> np.ndarray:
+        """Test hook (srcfd_model_debug_activation): raw 16-bit inter-kernel activations."""
+        out = np.empty(shape, dtype=dtype)
+        L.check(L.lib.srcfd_model_debug_activation(self._h, index, out.ctypes.data_as(C.c_void_p), out.nbytes))
+        return out
+
     def set_profiling(self, on: bool):
         L.check(L.lib.srcfd_model_set_profiling(self._h, int(on)))
 
