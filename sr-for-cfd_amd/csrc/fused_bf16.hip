@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -286,6 +287,7 @@ int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, cons
     tp.nan_guard = flags & SRCFD_FLAG_NAN_GUARD;
     tp.nonfinite = nonfinite;
     tp.out_dtype = out_dtype;
+    { const char* e = getenv("SRCFD_TAIL_ABLATE"); tp.ablate = e ? atoi(e) : 0; }
     const int blocks = std::min(c, fs->num_cus);
     rc = m.launch("tail(convT2-4+out)", s, [&] { return launch_tail16(f16, tp, blocks, s); });
     if (rc) return rc;

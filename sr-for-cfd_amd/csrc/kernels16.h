@@ -28,6 +28,7 @@ struct TailParams {
   int nan_guard;
   unsigned long long* nonfinite;
   int out_dtype;
+  int ablate;              // diagnostic builds only (SRCFD_TAIL_ABLATE): 1 no swish, 2 no D, 4 no A, 8 no BC
 };
 
 hipError_t launch_enc_conv1_16(bool f16, const float* x, const float* affine, const float* w, const float* b, uint16_t* y, int n, hipStream_t s);

@@ -207,18 +207,52 @@ __global__ void __launch_bounds__(256) gemm16(GemmDesc d, const uint16_t* __rest
 //   D(s-1): output 3x3 conv of the previous strip as a banded (Toeplitz) MFMA
 //          over 2x8-pixel tiles read from the ring, + de-standardise + guard
 // ---------------------------------------------------------------------------
-constexpr int T_RING_ROWS = 18, T_ROWP = 400 * 16;
+// LDS layouts are bank-swizzled for the two access patterns that hit them:
+//  ring (400-level, 16 B per pixel): a row is 8 planes (x & 7) of 50 granules
+//    (x >> 3).  BC writes a wave of pixels 4 apart in x (-> consecutive
+//    granules of two planes, 2-way at worst); D reads 16 tiles 8 apart in x
+//    (-> 16 consecutive granules, conflict-free; the row pitch is a multiple of
+//    256 B so the two window rows of one ds_read_b128 lane group interleave).
+//  L100 (100-level, 4 chunks of 8 channels): [chunk][row][x parity][x >> 1];
+//    A writes pixels 2 apart (-> consecutive), BC reads consecutive pixels
+//    (parity planes 56 granules = 8 mod 16 apart -> conflict-free).
+constexpr int T_RING_ROWS = 18, T_PLANE = 50, T_ROWP = 8 * T_PLANE * 16;
 constexpr int T_OFF_RING = 0;
 constexpr int T_OFF_L100 = T_RING_ROWS * T_ROWP;            // 115200
-constexpr int T_L100_ROW = 100 * 64, T_L100_BUF = 2 * T_L100_ROW;
-constexpr int T_OFF_CONST = T_OFF_L100 + 2 * T_L100_BUF;    // 140800: blob copied from TailParams::consts
+constexpr int T_L100_BUF = 4 * 212 * 16;                    // 13568
+constexpr int T_OFF_CONST = T_OFF_L100 + 2 * T_L100_BUF;    // blob copied from TailParams::consts
 constexpr int T_OFF_CTR = T_OFF_CONST + TAIL_CONST_BYTES;
-constexpr int T_LDS_BYTES = T_OFF_CTR + 16;
+constexpr int T_OFF_ZERO = T_OFF_CTR + 16;                  // 16 zero bytes: what out-of-image window pixels read
+constexpr int T_LDS_BYTES = T_OFF_ZERO + 16;
+static_assert(T_LDS_BYTES <= 160 * 1024, "tail kernel LDS budget");
 
+__device__ __forceinline__ int ring_off(int Y, int X) { return (Y % T_RING_ROWS) * T_ROWP + (((X & 7) * T_PLANE + (X >> 3)) << 4); }
+__device__ __forceinline__ int l100_off(int a, int x, int chunk) { return (chunk * 212 + a * 106 + (x & 1) * 56 + (x >> 1)) << 4; }
+
+// 16 swish + pack, issued as four batches of 16 independent instructions (exp, add, rcp, mul):
+// hipcc interleaves the four dependent steps of neighbouring elements, and with only four waves per
+// SIMD the in-order issue then stalls on every step (measured 25 cycles per 64 activations); in
+// batch order no instruction waits on one issued fewer than 16 slots earlier (~14 cycles).
 template <bool F16>
-__device__ __forceinline__ void swish_pack16(const f32x16& dd, uint32_t (&o)[8]) {
+__device__ __forceinline__ void swish_pack16(const f32x16& dd, uint32_t (&o)[8], bool skip = false) {
+  if (skip) {
 #pragma unroll
-  for (int i = 0; i < 8; ++i) o[i] = pack2<F16>(swish_scaled(dd[2 * i]), swish_scaled(dd[2 * i + 1]));
+    for (int i = 0; i < 8; ++i) o[i] = pack2<F16>(dd[2 * i], dd[2 * i + 1]);
+    return;
+  }
+  float u[16], e[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) u[i] = dd[i];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) e[i] = __builtin_amdgcn_exp2f(-u[i]);  // builtin: hipcc pads the MFMA -> VALU read hazard itself
+#pragma unroll
+  for (int i = 0; i < 16; ++i) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(e[i]));
+#pragma unroll
+  for (int i = 0; i < 16; ++i) asm volatile("v_rcp_f32 %0, %0" : "+v"(e[i]));
+#pragma unroll
+  for (int i = 0; i < 16; ++i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(e[i]) : "v"(u[i]));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = pack2<F16>(e[2 * i], e[2 * i + 1]);
 }
 
 __device__ __forceinline__ f32x16 load_bias16(const char* base) {
@@ -229,131 +263,214 @@ __device__ __forceinline__ f32x16 load_bias16(const char* base) {
   return r;
 }
 
+// block-wide barrier that leaves global loads / stores in flight: only LDS traffic
+// has to be complete before the other waves may look at it
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 template <bool F16, int OUT>  // OUT: 0 f32, 1 bf16, 2 f16
 __global__ void __launch_bounds__(1024) tail16(TailParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   char* ring = smem + T_OFF_RING;
   char* l100 = smem + T_OFF_L100;
   const char* cst = smem + T_OFF_CONST;
-  int* ctr = reinterpret_cast<int*>(smem + T_OFF_CTR);
 
   for (int i = tid; i < TAIL_CONST_BYTES / 16; i += 1024)
     reinterpret_cast<uint4*>(smem + T_OFF_CONST)[i] = reinterpret_cast<const uint4*>(p.consts)[i];
-  if (tid < 2) ctr[tid] = 0;
+  if (tid < 4) reinterpret_cast<int*>(smem + T_OFF_ZERO)[tid] = 0;
   __syncthreads();
 
   const uint4* wc_f = reinterpret_cast<const uint4*>(cst + TC_OFF_WC);
   const uint4* w3_f = reinterpret_cast<const uint4*>(cst + TC_OFF_W3);
-  const uint4* w4_f = reinterpret_cast<const uint4*>(cst + TC_OFF_W4);
   const uint4* w2_f = reinterpret_cast<const uint4*>(p.w2frags);
   const float conv_bias = *reinterpret_cast<const float*>(cst + TC_OFF_BC);
+  const uint4 w4 = reinterpret_cast<const uint4*>(cst + TC_OFF_W4)[lane];  // ConvT#4 operand stays in registers
+  // D-item lane constants: tile within the item, window sub-pixel (dy,dx) of this lane's k-group,
+  // byte offsets of the five window column pairs relative to granule (plane 0, tx)
+  const int d_tsel = 4 * (lane & 3) + ((lane & 15) >> 2), d_dy = (lane >> 4) & 1, d_dx = lane >> 5;
+  int d_xo[5];
+#pragma unroll
+  for (int cp = 0; cp < 5; ++cp)
+    d_xo[cp] = 16 * (d_dx ? (cp < 4 ? 2 * cp * T_PLANE : 1) : (cp == 0 ? 7 * T_PLANE - 1 : (2 * cp - 1) * T_PLANE));
 
-  int round = 0;
+  // ---- static schedule (per round: 14 BC, 8 A, 16 D items over 16 waves) ----
+  //   A : waves 0-7, item = wave; weights resident, activations prefetched one round ahead
+  //   BC: waves 8-15 -> item wave-8, waves 0-5 -> item 8+wave
+  //   D : waves 6,7 -> two items each; waves 8-11 -> two each; waves 12-15 -> one each
+  const bool hasA = wave < 8;
+  const int a_mt = wave & 3, a_ct = (wave >> 2) & 1;
+  const int bc_item = wave >= 8 ? wave - 8 : (wave < 6 ? 8 + wave : -1);
+  int d_first = 0, d_cnt = 0;
+  if (wave == 6 || wave == 7) { d_first = 2 * (wave - 6); d_cnt = 2; }
+  else if (wave >= 8 && wave < 12) { d_first = 4 + 2 * (wave - 8); d_cnt = 2; }
+  else if (wave >= 12) { d_first = wave; d_cnt = 1; }
+
+  const int a_px = 32 * a_ct + l31;
+  const bool a_valid = a_px < 50;
+  const int a_pxc = a_valid ? a_px : 49;
+  uint4 wa[4], xb[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) { wa[kk] = make_uint4(0, 0, 0, 0); xb[kk] = make_uint4(0, 0, 0, 0); }
+  if (hasA) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) wa[kk] = w2_f[(a_mt * 4 + kk) * 64 + lane];
+    if ((int)blockIdx.x < p.n) {
+      const uint16_t* src = p.in + ((size_t)blockIdx.x * 2500 + a_pxc) * 64 + 8 * h;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) xb[kk] = *reinterpret_cast<const uint4*>(src + 16 * kk);
+    }
+  }
+
+  const bool ab_sw = p.ablate & 1;
   for (int sample = blockIdx.x; sample < p.n; sample += gridDim.x) {
-    const uint16_t* in_s = p.in + (size_t)sample * 50 * 50 * 64;
     float o_mean = 0.f, o_std = 1.f;
-    if (p.aff_out) { o_mean = p.aff_out[2 * sample]; o_std = p.aff_out[2 * sample + 1]; }
+    if (p.aff_out) {
+      // wave-uniform: park them in SGPRs now, so no later use waits on vmcnt (which would also
+      // drain this wave's in-flight output stores and input prefetch)
+      o_mean = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.aff_out[2 * sample])));
+      o_std = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.aff_out[2 * sample + 1])));
+    }
     unsigned bad_count = 0;
 
-    for (int rho = 0; rho <= 52; ++rho, ++round) {
-      const int nBC = (rho >= 1 && rho <= 50) ? 14 : 0, nA = (rho <= 49) ? 8 : 0, nD = (rho >= 2) ? 13 : 0;
-      const int total = nBC + nA + nD;
-      if (tid == 0) ctr[(round + 1) & 1] = 0;
-      for (;;) {
-        int it = 0;
-        if (lane == 0) it = atomicAdd(&ctr[round & 1], 1);
-        it = __builtin_amdgcn_readfirstlane(it);
-        if (it >= total) break;
-
-        if (it < nBC) {
-          // ---------------- BC: ConvT#3 + ConvT#4 on 32 pixels of the 100-level ----------------
-          const int s = rho - 1, t = it >> 1, m3 = it & 1;
-          int idx = 32 * t + l31;
-          const bool valid = idx < 200;
-          if (!valid) idx = 199;
-          const int a = idx >= 100 ? 1 : 0, x100 = idx - 100 * a;
-          const char* src = l100 + (s & 1) * T_L100_BUF + (a * 100 + x100) * 64 + 16 * h;
-          uint4 b0 = *reinterpret_cast<const uint4*>(src), b1 = *reinterpret_cast<const uint4*>(src + 32);
-          f32x16 acc3 = load_bias16(cst + TC_OFF_B3 + h * 64);
-          acc3 = mfma32<F16>(w3_f[(m3 * 2 + 0) * 64 + lane], b0, acc3);
-          acc3 = mfma32<F16>(w3_f[(m3 * 2 + 1) * 64 + lane], b1, acc3);
-          uint32_t f3[8];
-          swish_pack16<F16>(acc3, f3);
-          const uint4 w4 = w4_f[lane];
-          const f32x16 bias4 = load_bias16(cst + TC_OFF_B4 + h * 64);
+    for (int rho = 0; rho <= 52; ++rho) {
+      // ---------------- BC: ConvT#3 + ConvT#4 on 32 pixels of the 100-level ----------------
+      auto do_bc = [&]() {
+        if (!(bc_item >= 0 && rho >= 1 && rho <= 50 && !(p.ablate & 8))) return;
+        const int s = rho - 1, t = bc_item >> 1, m3 = bc_item & 1;
+        int idx = 32 * t + l31;
+        const bool valid = idx < 200;
+        if (!valid) idx = 199;
+        const int a = idx >= 100 ? 1 : 0, x100 = idx - 100 * a;
+        const char* src = l100 + (s & 1) * T_L100_BUF;
+        uint4 b0 = *reinterpret_cast<const uint4*>(src + l100_off(a, x100, h)), b1 = *reinterpret_cast<const uint4*>(src + l100_off(a, x100, 2 + h));
+        f32x16 acc3 = load_bias16(cst + TC_OFF_B3 + h * 64);
+        acc3 = mfma32<F16>(w3_f[(m3 * 2 + 0) * 64 + lane], b0, acc3);
+        acc3 = mfma32<F16>(w3_f[(m3 * 2 + 1) * 64 + lane], b1, acc3);
+        uint32_t f3[8];
+        swish_pack16<F16>(acc3, f3, ab_sw);
+        // ring address = row slot (uniform base + small per-lane offset) + swizzled granule of x = 4*x100 + c
+        const int rbase = (8 * s) % T_RING_ROWS;
+        const int rowv = rbase + 4 * a;
+        char* wbase = ring + (((x100 & 1) * (4 * T_PLANE) + (x100 >> 1)) << 4) + 8 * h;
+        const f32x16 bias4 = load_bias16(cst + TC_OFF_B4 + h * 64);
 #pragma unroll
-          for (int tt = 0; tt < 2; ++tt) {
-            const int tap3 = 2 * m3 + tt, a3 = tap3 >> 1, b3 = tap3 & 1;
-            uint4 bf = make_uint4(f3[4 * tt], f3[4 * tt + 1], f3[4 * tt + 2], f3[4 * tt + 3]);
-            f32x16 acc4 = mfma32<F16>(w4, bf, bias4);
-            uint32_t f4[8];
-            swish_pack16<F16>(acc4, f4);
-            if (valid) {
+        for (int tt = 0; tt < 2; ++tt) {
+          const int tap3 = 2 * m3 + tt, a3 = tap3 >> 1, b3 = tap3 & 1;
+          uint4 bf = make_uint4(f3[4 * tt], f3[4 * tt + 1], f3[4 * tt + 2], f3[4 * tt + 3]);
+          f32x16 acc4 = mfma32<F16>(w4, bf, bias4);
+          uint32_t f4[8];
+          swish_pack16<F16>(acc4, f4, ab_sw);
+          if (valid) {
 #pragma unroll
-              for (int q = 0; q < 4; ++q) {
-                const int Y = 8 * s + 4 * a + 2 * a3 + (q >> 1), X = 4 * x100 + 2 * b3 + (q & 1);
-                *reinterpret_cast<uint2*>(ring + (Y % T_RING_ROWS) * T_ROWP + X * 16 + 8 * h) = make_uint2(f4[2 * q], f4[2 * q + 1]);
-              }
+            for (int q = 0; q < 4; ++q) {
+              int rr = rowv + 2 * a3 + (q >> 1);
+              rr = rr >= T_RING_ROWS ? rr - T_RING_ROWS : rr;
+              *reinterpret_cast<uint2*>(wbase + rr * T_ROWP + (2 * b3 + (q & 1)) * (T_PLANE * 16)) = make_uint2(f4[2 * q], f4[2 * q + 1]);
             }
           }
-        } else if (it < nBC + nA) {
-          // ---------------- A: ConvT#2 for strip rho, global -> LDS ----------------
-          const int s = rho, item = it - nBC, mt = item & 3, ct = item >> 2;
-          const int px = 32 * ct + l31;
-          const bool valid = px < 50;
-          const uint16_t* src = in_s + ((size_t)s * 50 + (valid ? px : 49)) * 64 + 8 * h;
-          f32x16 acc = load_bias16(cst + TC_OFF_B2 + h * 64);
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) {
-            uint4 b = *reinterpret_cast<const uint4*>(src + 16 * kk);
-            acc = mfma32<F16>(w2_f[(mt * 4 + kk) * 64 + lane], b, acc);
-          }
-          uint32_t f2[8];
-          swish_pack16<F16>(acc, f2);
-          if (valid) {
-            const int a = mt >> 1, x100 = 2 * px + (mt & 1);
-            char* dst = l100 + (s & 1) * T_L100_BUF + (a * 100 + x100) * 64 + 8 * h;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(dst + 16 * q) = make_uint2(f2[2 * q], f2[2 * q + 1]);
-          }
-        } else {
-          // ---------------- D: output conv of strip rho-2, rows 8s-1 .. 8s+6 ----------------
-          const int s = rho - 2, j = it - nBC - nA;
-          const int m = lane & 15, kg = lane >> 4;
-          int T = 16 * j + 4 * (m & 3) + (m >> 2);
-          if (T > 199) T = 199;
-          const int rp = T / 50, tx = T - 50 * rp;
-          const int Yt = 8 * s - 1 + 2 * rp;  // first output row of the tile
+        }
+      };
+
+      // ---------------- D: output conv of strip rho-2, rows 8s-1 .. 8s+6 ----------------
+      // One item = one output row pair (rp, wave-uniform) x 16 tiles of 2x8 pixels, so row
+      // slots / validity live in SGPRs and each lane only adds its own column offset.
+      const bool d_on = rho >= 2 && !(p.ablate & 2);
+      {
+        auto do_d = [&](const int item) {  // called (not looped) so no conservative vmcnt(0) lands in front of it
+          const int s = rho - 2, rp = item >> 2, j4 = item & 3;
+          const int kg = lane >> 4;
+          int tx = 16 * j4 + d_tsel;
+          tx = tx < 50 ? tx : 49;
+          const int Ya = 8 * s - 2 + 2 * rp;  // first window row (dy = 0)
+          const int sa = (8 * s + 16 + 2 * rp) % T_RING_ROWS;
+          const int Y0 = Ya + d_dy, Y1 = Y0 + 2;
+          int s0 = sa + d_dy, s1 = s0 + 2;
+          s0 = s0 >= T_RING_ROWS ? s0 - T_RING_ROWS : s0;
+          s1 = s1 >= T_RING_ROWS ? s1 - T_RING_ROWS : s1;
+          const int r0 = T_OFF_RING + s0 * T_ROWP + tx * 16, r1 = T_OFF_RING + s1 * T_ROWP + tx * 16;
+          const bool okf = !(d_dx == 0 && tx == 0), okl = !(d_dx == 1 && tx == 49);
+          const bool interior = s >= 1 && s <= 49;  // wave-uniform: only the image's left/right edge can be outside
+          const bool ok0 = interior || (unsigned)Y0 < 400u, ok1 = interior || (unsigned)Y1 < 400u;
           f32x4 acc = {conv_bias, conv_bias, conv_bias, conv_bias};
 #pragma unroll
-          for (int kk = 0; kk < 10; ++kk) {
-            const int wy = 2 * (kk / 5) + (kg & 1), wx = 2 * (kk % 5) + (kg >> 1);
-            const int Yw = Yt - 1 + wy, Xw = 8 * tx - 1 + wx;
-            const bool ok = Yw >= 0 && Yw < 400 && Xw >= 0 && Xw < 400;
-            uint4 av = make_uint4(0, 0, 0, 0);
-            if (ok) av = *reinterpret_cast<const uint4*>(ring + (Yw % T_RING_ROWS) * T_ROWP + Xw * 16);
-            acc = mfma16<F16>(av, wc_f[kk * 64 + lane], acc);
-          }
-          const int oy = m >> 3, ox = m & 7;
+          for (int half = 0; half < 2; ++half) {  // two batches of five k-steps keep the live operand set at 40 VGPRs
+            uint4 av[5], wv[5];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int To = 16 * j + 4 * r + kg;
-            if (To > 199) continue;
-            const int rpo = To / 50, txo = To - 50 * rpo;
-            const int Y = 8 * s - 1 + 2 * rpo + oy, X = 8 * txo + ox;
-            if (Y < 0 || Y >= 400) continue;
-            float v = acc[r];
-            if (p.aff_out) v = __fadd_rn(__fmul_rn(v, o_std), o_mean);
-            if (p.nan_guard && !(fabsf(v) <= 3.402823466e38f)) { v = 0.f; ++bad_count; }
-            const size_t o = ((size_t)sample * 400 + Y) * 400 + X;
-            if (OUT == 0) reinterpret_cast<float*>(p.out)[o] = v;
-            else if (OUT == 1) reinterpret_cast<uint16_t*>(p.out)[o] = (uint16_t)(pack2<false>(v, 0.f) & 0xffff);
-            else reinterpret_cast<uint16_t*>(p.out)[o] = (uint16_t)(pack2<true>(v, 0.f) & 0xffff);
+            for (int cp = 0; cp < 5; ++cp) {
+              bool ok = half ? ok1 : ok0;
+              if (cp == 0) ok = ok && okf;
+              if (cp == 4) ok = ok && okl;
+              const int off = ok ? (half ? r1 : r0) + d_xo[cp] : T_OFF_ZERO;
+              av[cp] = *reinterpret_cast<const uint4*>(smem + off);
+              wv[cp] = wc_f[(half * 5 + cp) * 64 + lane];
+            }
+#pragma unroll
+            for (int cp = 0; cp < 5; ++cp) acc = mfma16<F16>(av[cp], wv[cp], acc);
+            __builtin_amdgcn_sched_barrier(0);
           }
+          // accumulator register r of lane group kg holds tile 16*j4 + 4r + kg, pixel (oy,ox) = lane & 15
+          const int oy = (lane >> 3) & 1, ox = lane & 7;
+          const int Y = 8 * s - 1 + 2 * rp + oy;
+          const int txo = 16 * j4 + kg;
+          if ((unsigned)Y < 400u) {
+            const size_t o0 = ((size_t)sample * 400 + Y) * 400 + 8 * txo + ox;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              if (txo + 4 * r >= 50) continue;
+              float v = acc[r];
+              if (p.aff_out) v = __fadd_rn(__fmul_rn(v, o_std), o_mean);
+              if (p.nan_guard && !(fabsf(v) <= 3.402823466e38f)) { v = 0.f; ++bad_count; }
+              const size_t o = o0 + 32 * r;
+              if (OUT == 0) reinterpret_cast<float*>(p.out)[o] = v;
+              else if (OUT == 1) reinterpret_cast<uint16_t*>(p.out)[o] = (uint16_t)(pack2<false>(v, 0.f) & 0xffff);
+              else reinterpret_cast<uint16_t*>(p.out)[o] = (uint16_t)(pack2<true>(v, 0.f) & 0xffff);
+            }
+          }
+        };
+        // stagger: the BC-only-plus-D waves do their latency-bound D items first, so their VALU-heavy
+        // BC items overlap the tail (A items) of the waves that started with BC
+        if (wave >= 8) {
+          if (d_on && d_cnt >= 1) do_d(d_first);
+          if (d_on && d_cnt >= 2) do_d(d_first + 1);
+        }
+        do_bc();
+        if (wave < 8) {
+          if (d_on && d_cnt >= 1) do_d(d_first);
+          if (d_on && d_cnt >= 2) do_d(d_first + 1);
         }
       }
-      __syncthreads();
+
+      // ---------------- A: ConvT#2 for strip rho (input prefetched last round), then prefetch ----------------
+      if (hasA && rho <= 49 && !(p.ablate & 4)) {
+        const int s = rho;
+        f32x16 acc = load_bias16(cst + TC_OFF_B2 + h * 64);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) acc = mfma32<F16>(wa[kk], xb[kk], acc);
+        // next strip of this sample, or the first strip of this workgroup's next sample
+        {
+          int ns = sample, nr = rho + 1;
+          if (nr > 49) { ns = sample + gridDim.x; nr = 0; }
+          if (ns < p.n) {
+            const uint16_t* src = p.in + (((size_t)ns * 50 + nr) * 50 + a_pxc) * 64 + 8 * h;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) xb[kk] = *reinterpret_cast<const uint4*>(src + 16 * kk);
+          }
+        }
+        uint32_t f2[8];
+        swish_pack16<F16>(acc, f2, ab_sw);
+        if (a_valid) {
+          const int a = a_mt >> 1, x100 = 2 * a_px + (a_mt & 1);
+          char* dst = l100 + (s & 1) * T_L100_BUF + 8 * h;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(dst + l100_off(a, x100, q)) = make_uint2(f2[2 * q], f2[2 * q + 1]);
+        }
+      }
+      lds_barrier();
     }
     if (p.nan_guard && p.nonfinite && bad_count) atomicAdd(p.nonfinite, (unsigned long long)bad_count);
   }

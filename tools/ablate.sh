@@ -1,0 +1,6 @@
+#!/bin/bash
+# Tail-kernel ablation (diagnostic): times bench.py with parts of the tail switched off.
+for A in 0 1 2 4 8 6 14 15; do
+  SRCFD_TAIL_ABLATE=$A python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('ablate=$A tail ms', d['kernels_ms']['tail(convT2-4+out)'])"
+done
