@@ -137,8 +137,9 @@ int srcfd_model_set_profiling(srcfd_model* m, int enable);
 int srcfd_model_get_profile(srcfd_model* m, char* names, size_t names_len, float* ms, int* count, int max_count);
 /* Test hook: copies the first `bytes` of inter-kernel activation buffer `index`
  * (0 or 1) of the bf16/f16 pipeline to host memory after synchronising.  After a
- * forward, buffer 0 holds ConvT#1's output (n,50,50,64) and buffer 1 ConvT#0's
- * (n,25,25,128), both 16-bit and scaled by log2(e). */
+ * forward, index 0 is ConvT#1's output (n,50,50,64), 16-bit, scaled by log2(e); index 1
+ * is ConvT#0's (n,25,25,128) only when the generic GEMM path ran (env SRCFD_MID=0) --
+ * the default fused ConvT#0->ConvT#1 kernel never materialises it. */
 int srcfd_model_debug_activation(srcfd_model* m, int index, void* dst, size_t bytes);
 
 /* ---- stats file ----------------------------------------------------------

@@ -1,0 +1,77 @@
+// Device-side helpers shared by the 16-bit kernels (kernels_bf16.hip, kernels_mid16.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/srcfd.h"
+
+namespace srcfd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+
+template <bool F16>
+__device__ __forceinline__ f32x16 mfma32(const uint4& a, const uint4& b, const f32x16& c) {
+  if (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b), c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, const f32x4& c) {
+  if (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b), c, 0, 0, 0);
+}
+
+template <bool F16>
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  f32x2 v = {lo, hi};
+  if (F16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, h16x2));
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));  // v_cvt_pk_bf16_f32, RNE
+}
+
+// u = log2e * x  ->  log2e * swish(x)
+__device__ __forceinline__ float swish_scaled(float u) {
+  float e = __builtin_amdgcn_exp2f(-u);
+  return u * __builtin_amdgcn_rcpf(1.0f + e);
+}
+__device__ __forceinline__ float act16(float u, int act) { return act == SRCFD_ACT_SWISH ? swish_scaled(u) : u; }
+
+// 16 swish + pack, issued as four batches of 16 independent instructions (exp, add, rcp, mul):
+// hipcc interleaves the four dependent steps of neighbouring elements, and with only four waves per
+// SIMD the in-order issue then stalls on every step (measured 25 cycles per 64 activations); in
+// batch order no instruction waits on one issued fewer than 16 slots earlier (~14 cycles).
+template <bool F16>
+__device__ __forceinline__ void swish_pack16(const f32x16& dd, uint32_t (&o)[8], bool skip = false) {
+  if (skip) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = pack2<F16>(dd[2 * i], dd[2 * i + 1]);
+    return;
+  }
+  float u[16], e[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) u[i] = dd[i];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) e[i] = __builtin_amdgcn_exp2f(-u[i]);  // builtin: hipcc pads the MFMA -> VALU read hazard itself
+#pragma unroll
+  for (int i = 0; i < 16; ++i) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(e[i]));
+#pragma unroll
+  for (int i = 0; i < 16; ++i) asm volatile("v_rcp_f32 %0, %0" : "+v"(e[i]));
+#pragma unroll
+  for (int i = 0; i < 16; ++i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(e[i]) : "v"(u[i]));
+#pragma unroll
+  for (int i = 0; i < 8; ++i) o[i] = pack2<F16>(e[2 * i], e[2 * i + 1]);
+}
+
+__device__ __forceinline__ f32x16 load_bias16(const char* base) {
+  f32x16 r;
+  const float4* p = reinterpret_cast<const float4*>(base);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { float4 v = p[i]; r[4 * i] = v.x; r[4 * i + 1] = v.y; r[4 * i + 2] = v.z; r[4 * i + 3] = v.w; }
+  return r;
+}
+
+}  // namespace srcfd

@@ -54,6 +54,8 @@ struct Pack16 {  // one per operand type (bf16, f16)
   uint16_t* d_w = nullptr;
   void* d_consts = nullptr;
   void* d_w2f = nullptr;
+  void* d_w1f = nullptr;   // mid16: ConvT#1 operands
+  float* d_midb = nullptr; // mid16: bias fragments (b0f 128 floats, then b1f 64 floats)
   bool built = false;
 };
 
@@ -65,7 +67,10 @@ struct FusedState {
   float* d_f32 = nullptr;
   Pack16 packs[2];
   uint16_t* act[2] = {nullptr, nullptr};
+  float* d_part = nullptr;  // split-K partial-sum slabs
+  size_t part_elems = 0;
   int cap = 0;
+  int t1_buf = 0;  // which act[] holds ConvT#1's output after the last forward
   int num_cus = 256;
 };
 
@@ -111,8 +116,8 @@ int fused_init(Model& m) {
     if (ci == 3) { o.d.N = 64; o.d.CO = 64; o.d.OC = 64; }   // latent 50 -> 64 zero-padded channels
     if (ci == 4) { o.d.CI = 64; o.d.K = 64; }                // dense_1 reads the padded latent
     o.d.Npad = (o.d.N + 63) / 64 * 64;
-    o.Kpad = (o.d.K + 31) / 32 * 32;
-    if (o.d.CI % 32 != 0 || o.d.K % 32 != 0 || o.d.N % 4 != 0 || o.d.CO % 4 != 0) { set_error("fused path: unsupported channel count in " + op.name); return SRCFD_EINVAL; }
+    o.Kpad = (o.d.K + 63) / 64 * 64;
+    if (o.d.CI % 64 != 0 || o.d.K % 64 != 0 || o.d.N % 4 != 0 || o.d.CO % 4 != 0) { set_error("fused path: unsupported channel count in " + op.name); return SRCFD_EINVAL; }
     const double so = scale_out(md, fs->cl, ci);
     while (fs->f32.size() % 4) fs->f32.push_back(0.f);
     o.b_off = fs->f32.size();
@@ -211,6 +216,33 @@ static int build_pack(Model& m, FusedState* fs, bool f16) {
       }
   HIPCHECK(hipMalloc(&P.d_w2f, w2.size() * sizeof(uint16_t)));
   HIPCHECK(hipMemcpy(P.d_w2f, w2.data(), w2.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  // ---- mid16 (ConvT#0 -> ConvT#1) operands ----
+  {
+    const Layer& L0 = md.layers[fs->cl[5]];  // ConvT 256->128 (bias only; weights reuse the per-phase GEMM packing)
+    const Layer& L1 = md.layers[fs->cl[6]];  // ConvT 128->64, kernel (2,2,64,128)
+    std::vector<uint16_t> w1((size_t)8 * 8 * 64 * 8);
+    for (int j8 = 0; j8 < 8; ++j8)
+      for (int st = 0; st < 8; ++st)
+        for (int l = 0; l < 64; ++l) {
+          int i = l & 31, hh = l >> 5, tap = j8 >> 1, co = 32 * (j8 & 1) + i;
+          for (int j = 0; j < 8; ++j) {
+            // k-step st consumes accumulator tile st>>1, registers 8*(st&1)+j: channel of that register
+            int ci = 32 * (st >> 1) + 16 * (st & 1) + 8 * (j >> 2) + 4 * hh + (j & 3);
+            w1[(((size_t)j8 * 8 + st) * 64 + l) * 8 + j] = to16(L1.kernel[((size_t)tap * 64 + co) * 128 + ci], f16);
+          }
+        }
+    HIPCHECK(hipMalloc(&P.d_w1f, w1.size() * sizeof(uint16_t)));
+    HIPCHECK(hipMemcpy(P.d_w1f, w1.data(), w1.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    std::vector<float> mb(128 + 64);
+    for (int mt = 0; mt < 4; ++mt)
+      for (int hh = 0; hh < 2; ++hh)
+        for (int r = 0; r < 16; ++r) mb[(mt * 2 + hh) * 16 + r] = (float)(L0.bias[32 * mt + rowof(r, hh)] * LOG2E);
+    for (int jj = 0; jj < 2; ++jj)
+      for (int hh = 0; hh < 2; ++hh)
+        for (int r = 0; r < 16; ++r) mb[128 + (jj * 2 + hh) * 16 + r] = (float)(L1.bias[32 * jj + rowof(r, hh)] * LOG2E);
+    HIPCHECK(hipMalloc(&P.d_midb, mb.size() * sizeof(float)));
+    HIPCHECK(hipMemcpy(P.d_midb, mb.data(), mb.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
   P.built = true;
   return SRCFD_OK;
 }
@@ -222,9 +254,12 @@ void fused_free(Model& m) {
     if (P.d_w) (void)hipFree(P.d_w);
     if (P.d_consts) (void)hipFree(P.d_consts);
     if (P.d_w2f) (void)hipFree(P.d_w2f);
+    if (P.d_w1f) (void)hipFree(P.d_w1f);
+    if (P.d_midb) (void)hipFree(P.d_midb);
   }
   if (fs->d_f32) (void)hipFree(fs->d_f32);
   for (auto* b : fs->act) if (b) (void)hipFree(b);
+  if (fs->d_part) (void)hipFree(fs->d_part);
   delete fs;
   m.fused = nullptr;
 }
@@ -235,7 +270,7 @@ int fused_debug_read(Model& m, int index, void* dst, size_t bytes) {
   if (bytes > (size_t)fs->cap * 160000 * sizeof(uint16_t)) { set_error("read past the activation buffer"); return SRCFD_EINVAL; }
   HIPCHECK(hipSetDevice(m.device));
   HIPCHECK(hipDeviceSynchronize());
-  HIPCHECK(hipMemcpy(dst, fs->act[index], bytes, hipMemcpyDeviceToHost));
+  HIPCHECK(hipMemcpy(dst, fs->act[index == 0 ? fs->t1_buf : fs->t1_buf ^ 1], bytes, hipMemcpyDeviceToHost));
   return SRCFD_OK;
 }
 
@@ -254,6 +289,9 @@ int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, cons
     for (auto*& b : fs->act) if (b) { HIPCHECK(hipFree(b)); b = nullptr; }
     fs->cap = 0;
     for (auto*& b : fs->act) HIPCHECK(hipMalloc(&b, (size_t)want * ACT_ELEMS * sizeof(uint16_t)));
+    if (fs->d_part) { HIPCHECK(hipFree(fs->d_part)); fs->d_part = nullptr; }
+    fs->part_elems = (size_t)16 * want * 128;  // dense(3200->128): up to 16 K-slice slabs of (rows x 128) f32
+    HIPCHECK(hipMalloc(&fs->d_part, fs->part_elems * sizeof(float)));
     fs->cap = want;
   }
   const size_t osz = out_dtype == SRCFD_F32 ? 4 : 2;
@@ -265,18 +303,40 @@ int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, cons
     int cur = 0;
     rc = m.launch("conv2d", s, [&] { return launch_enc_conv1_16(f16, xin, ain, fs->d_f32 + fs->c1w_off, fs->d_f32 + fs->c1b_off, fs->act[0], c, s); });
     if (rc) return rc;
+    const bool use_mid = [] { const char* e = getenv("SRCFD_MID"); return !e || atoi(e) != 0; }();  // 0: generic GEMMs (A/B, tests)
     int prev_layer = -1;
     for (const Op16& o : fs->ops) {
+      if (use_mid && o.layer >= 5) break;  // ConvT#0 / ConvT#1 run in the fused mid kernel below
       if (o.layer != prev_layer && prev_layer >= 0) cur ^= 1;
       prev_layer = o.layer;
       GemmDesc d = o.d;
       d.M = c * d.MH * d.MW;
       const uint16_t* X = fs->act[cur];
       uint16_t* Y = fs->act[cur ^ 1];
-      rc = m.launch(o.name.c_str(), s, [&] { return launch_gemm16(f16, d, X, P.d_w + o.w_off, o.Kpad, fs->d_f32 + o.b_off, Y, s); });
+      // dense layers with few rows and a long K: split K over workgroups (f32 slabs + finish kernel)
+      int splits = 1;
+      if (d.MH == 1 && d.MW == 1 && d.K >= 1024) splits = std::max(1, std::min(16, d.K / 256));
+      if (splits > 1 && (size_t)splits * d.M * d.Npad > fs->part_elems) splits = 1;
+      rc = m.launch(o.name.c_str(), s, [&] { return launch_gemm16(f16, d, X, P.d_w + o.w_off, o.Kpad, fs->d_f32 + o.b_off, Y, fs->d_part, splits, s); });
+      if (rc) return rc;
+    }
+    if (use_mid) {
+      cur ^= 1;  // dense_1 output
+      MidParams mp;
+      mp.in = fs->act[cur];
+      mp.out = fs->act[cur ^ 1];
+      mp.n = c;
+      int ph = 0;
+      for (const Op16& o : fs->ops)
+        if (o.layer == 5) { mp.w0[ph] = P.d_w + o.w_off; mp.kpad[ph] = o.Kpad; ++ph; }
+      mp.b0f = P.d_midb;
+      mp.w1f = P.d_w1f;
+      mp.b1f = P.d_midb + 128;
+      rc = m.launch("mid(convT0+convT1)", s, [&] { return launch_mid16(f16, mp, s); });
       if (rc) return rc;
     }
     cur ^= 1;
+    fs->t1_buf = cur;
     TailParams tp;
     tp.in = fs->act[cur];
     tp.out = (char*)y_dev + (size_t)i0 * 160000 * osz;

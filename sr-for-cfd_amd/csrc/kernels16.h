@@ -31,8 +31,24 @@ struct TailParams {
   int ablate;              // diagnostic builds only (SRCFD_TAIL_ABLATE): 1 no swish, 2 no D, 4 no A, 8 no BC
 };
 
+// ConvT#0 -> ConvT#1 fused kernel (kernels_mid16.hip)
+struct MidParams {
+  const uint16_t* in;      // (n,12,12,256) dense_1 output, scaled by log2e
+  uint16_t* out;           // (n,50,50,64) ConvT#1 output, scaled by log2e
+  int n;
+  const uint16_t* w0[4];   // per output phase (py*2+px): ConvT#0 weights [128 ch][kpad], k = tap*256 + ci
+  int kpad[4];
+  const float* b0f;        // ConvT#0 bias as accumulator init [m-tile 4][lane half 2][16]
+  const void* w1f;         // ConvT#1 A operands [m-tile 8][k-step 8][64 lanes] x 16 B, k in accumulator order
+  const float* b1f;        // ConvT#1 bias as accumulator init [channel half 2][lane half 2][16]
+};
+hipError_t launch_mid16(bool f16, const MidParams& p, hipStream_t s);
+
 hipError_t launch_enc_conv1_16(bool f16, const float* x, const float* affine, const float* w, const float* b, uint16_t* y, int n, hipStream_t s);
-hipError_t launch_gemm16(bool f16, const GemmDesc& d, const uint16_t* X, const uint16_t* Wt, int Kpad, const float* bias, uint16_t* Y, hipStream_t s);
+// part/splits: optional split-K (dense layers with few rows): one f32 slab (M x Npad) per K slice in `part`,
+// summed in slice order by a finish kernel (deterministic)
+hipError_t launch_gemm16(bool f16, const GemmDesc& d, const uint16_t* X, const uint16_t* Wt, int Kpad, const float* bias, uint16_t* Y,
+                         float* part, int splits, hipStream_t s);
 hipError_t launch_tail16(bool f16, const TailParams& p, int blocks, hipStream_t s);
 int tail_lds_bytes();
 

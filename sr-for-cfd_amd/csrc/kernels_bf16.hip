@@ -16,42 +16,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "dev16.h"
 #include "kernels16.h"
 
 namespace srcfd {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
-
-template <bool F16>
-__device__ __forceinline__ f32x16 mfma32(const uint4& a, const uint4& b, const f32x16& c) {
-  if (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b), c, 0, 0, 0);
-}
-template <bool F16>
-__device__ __forceinline__ f32x4 mfma16(const uint4& a, const uint4& b, const f32x4& c) {
-  if (F16) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h16x8, a), __builtin_bit_cast(h16x8, b), c, 0, 0, 0);
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b), c, 0, 0, 0);
-}
-
-template <bool F16>
-__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-  f32x2 v = {lo, hi};
-  if (F16) return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, h16x2));
-  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));  // v_cvt_pk_bf16_f32, RNE
-}
-
-// u = log2e * x  ->  log2e * swish(x)
-__device__ __forceinline__ float swish_scaled(float u) {
-  float e = __builtin_amdgcn_exp2f(-u);
-  return u * __builtin_amdgcn_rcpf(1.0f + e);
-}
-__device__ __forceinline__ float act16(float u, int act) { return act == SRCFD_ACT_SWISH ? swish_scaled(u) : u; }
 
 // ---------------------------------------------------------------------------
 // encoder conv #1: x (n,10,10,1) f32 [+ standardise] -> (n,5,5,64) bf16/f16
@@ -94,21 +62,34 @@ __global__ void __launch_bounds__(256) enc_conv1_16(const float* __restrict__ x,
 
 // ---------------------------------------------------------------------------
 // implicit GEMM, 16-bit operands.  D[channel][pixel] = Wt[channel][k] * X[pixel][k]
-// Block 256 threads; tile 128 pixels x BN channels x 32 k.
+// Block 256 threads; tile 128 pixels x BN channels x 64 k; one LDS stage (37 KB) with the
+// next k-tile's global loads held in registers while the current one feeds the MFMAs, and
+// <= 128 VGPRs, so four workgroups share a CU: these layers are bound by memory latency
+// (a k-tile is ~0.5k cycles of MFMA against ~5k cycles of load latency), and in-flight
+// loads per CU is what buys time.  LDS rows are 144 B (64 elements + 8 pad): a
+// ds_read_b128 lane group then covers 16 distinct 16-byte slots of the 256-byte bank row.
+// SPLITK: blockIdx.z takes a K slice and adds f32 partial sums into `part`
+// (zeroed by the caller); splitk_finish16 applies bias + activation.
 // ---------------------------------------------------------------------------
-constexpr int G_BP = 128, G_BK = 32, G_PITCH = 40;  // LDS row pitch in elements (80 B: conflict-free b128 reads)
+constexpr int G_BP = 128, G_BK = 64, G_PITCH = 72;
 
-template <bool F16, int BN>
-__global__ void __launch_bounds__(256) gemm16(GemmDesc d, const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wt, int Kpad,
-                                               const float* __restrict__ bias, uint16_t* __restrict__ Y) {
+template <bool F16, int BN, bool SPLITK>
+__global__ void __launch_bounds__(256, 4) gemm16(GemmDesc d, const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wt, int Kpad,
+                                               const float* __restrict__ bias, uint16_t* __restrict__ Y, float* __restrict__ part, int kslice) {
   constexpr int PT = BN == 128 ? 2 : 1;  // 32-pixel tiles per wave
-  __shared__ __attribute__((aligned(16))) uint16_t Xs[G_BP * G_PITCH];
-  __shared__ __attribute__((aligned(16))) uint16_t Ws[BN * G_PITCH];
-  __shared__ int row_img[G_BP], row_my[G_BP], row_mx[G_BP];
+  constexpr int WCH = BN / 64;           // 16-byte weight chunks per thread and k-tile
+  extern __shared__ __attribute__((aligned(16))) char gsm[];
+  uint16_t* Xs = reinterpret_cast<uint16_t*>(gsm);                       // [G_BP][G_PITCH]
+  uint16_t* Ws = Xs + G_BP * G_PITCH;                                    // [BN][G_PITCH]
+  int* row_img = reinterpret_cast<int*>(Ws + BN * G_PITCH);              // [G_BP] x3
+  int* row_my = row_img + G_BP;
+  int* row_mx = row_my + G_BP;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
   const int wc = BN == 128 ? (wave >> 1) : 0, wp = BN == 128 ? (wave & 1) : wave;
   const int m0 = blockIdx.x * G_BP, n0 = blockIdx.y * BN;
+  const int kbeg = SPLITK ? blockIdx.z * kslice : 0;
+  const int kend = SPLITK ? min(d.K, kbeg + kslice) : d.K;
 
   if (tid < G_BP) {
     int m = m0 + tid, img = -1, my = 0, mx = 0;
@@ -123,6 +104,51 @@ __global__ void __launch_bounds__(256) gemm16(GemmDesc d, const uint16_t* __rest
   }
   __syncthreads();
 
+  // this thread's four X chunks: rows (tid>>3) + 32j, 16-byte column tid&7.  Everything that
+  // does not change with the k-tile is folded into 32-bit element offsets up front, so a k-tile
+  // costs one add (+ two compares when the tap can fall outside the image) per 16-byte load.
+  const int xrow = tid >> 3, c8 = tid & 7;
+  const bool check = d.TY * d.TX > 1 || d.cy != 0 || d.cx != 0;  // taps that can leave the image
+  int xoff[4], xy[4], xx[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    int img = row_img[xrow + 32 * j];
+    int by0 = row_my[xrow + 32 * j] * d.ay + d.cy, bx0 = row_mx[xrow + 32 * j] * d.ax + d.cx;
+    xy[j] = img >= 0 ? by0 : -(1 << 28);  // rows past M never pass the bounds test
+    xx[j] = bx0;
+    xoff[j] = ((img * d.IH + by0) * d.IW + bx0) * d.CI + c8 * 8;
+    if (!check && img < 0) xoff[j] = c8 * 8;  // dense / k==s layers: read row 0, result is discarded
+  }
+  int woff[2 * (BN / 64)];
+#pragma unroll
+  for (int j = 0; j < 2 * (BN / 64); ++j) woff[j] = (n0 + xrow + 32 * j) * Kpad + c8 * 8;
+  const int lds_x = xrow * G_PITCH + c8 * 8;  // + 32j rows
+
+  uint4 xr[4], wr[WCH * 2];
+  auto g2r = [&](int k0) {
+    int tap = k0 / d.CI, ci0 = k0 - tap * d.CI;
+    int ty = tap / d.TX, tx = tap - ty * d.TX;
+    const int dy = ty * d.by, dx = tx * d.bx;
+    const int toff = (dy * d.IW + dx) * d.CI + ci0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (!check || ((unsigned)(xy[j] + dy) < (unsigned)d.IH && (unsigned)(xx[j] + dx) < (unsigned)d.IW))
+        v = *reinterpret_cast<const uint4*>(X + (xoff[j] + toff));
+      xr[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < WCH * 2; ++j) wr[j] = *reinterpret_cast<const uint4*>(Wt + (woff[j] + k0));
+  };
+  auto r2l = [&]() {
+    uint16_t* xs = Xs + lds_x;
+    uint16_t* ws = Ws + lds_x;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<uint4*>(xs + 32 * j * G_PITCH) = xr[j];
+#pragma unroll
+    for (int j = 0; j < WCH * 2; ++j) *reinterpret_cast<uint4*>(ws + 32 * j * G_PITCH) = wr[j];
+  };
+
   f32x16 acc[2][PT];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -131,35 +157,20 @@ __global__ void __launch_bounds__(256) gemm16(GemmDesc d, const uint16_t* __rest
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  for (int k0 = 0; k0 < d.K; k0 += G_BK) {
-    int tap = k0 / d.CI, ci0 = k0 - tap * d.CI;
-    int ty = tap / d.TX, tx = tap - ty * d.TX;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      int c = tid + 256 * j, row = c >> 2, c4 = c & 3;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      int img = row_img[row];
-      if (img >= 0) {
-        int iy = row_my[row] * d.ay + ty * d.by + d.cy, ix = row_mx[row] * d.ax + tx * d.bx + d.cx;
-        if (iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW)
-          v = *reinterpret_cast<const uint4*>(X + (((int64_t)img * d.IH + iy) * d.IW + ix) * d.CI + ci0 + c4 * 8);
-      }
-      *reinterpret_cast<uint4*>(Xs + row * G_PITCH + c4 * 8) = v;
-    }
-#pragma unroll
-    for (int j = 0; j < BN / 64; ++j) {
-      int c = tid + 256 * j, row = c >> 2, c4 = c & 3;
-      uint4 v = *reinterpret_cast<const uint4*>(Wt + (int64_t)(n0 + row) * Kpad + k0 + c4 * 8);
-      *reinterpret_cast<uint4*>(Ws + row * G_PITCH + c4 * 8) = v;
-    }
+  g2r(kbeg);
+  const uint16_t* xs = Xs + (wp * 32 * PT + l31) * G_PITCH + h * 8;
+  const uint16_t* ws = Ws + (wc * 64 + l31) * G_PITCH + h * 8;
+  for (int k0 = kbeg; k0 < kend; k0 += G_BK) {
+    r2l();
     __syncthreads();
+    if (k0 + G_BK < kend) g2r(k0 + G_BK);
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < 4; ++kk) {
       uint4 af[2], bf[PT];
 #pragma unroll
-      for (int a = 0; a < 2; ++a) af[a] = *reinterpret_cast<const uint4*>(Ws + (wc * 64 + a * 32 + l31) * G_PITCH + kk * 16 + h * 8);
+      for (int a = 0; a < 2; ++a) af[a] = *reinterpret_cast<const uint4*>(ws + a * 32 * G_PITCH + kk * 16);
 #pragma unroll
-      for (int b = 0; b < PT; ++b) bf[b] = *reinterpret_cast<const uint4*>(Xs + (wp * 32 * PT + b * 32 + l31) * G_PITCH + kk * 16 + h * 8);
+      for (int b = 0; b < PT; ++b) bf[b] = *reinterpret_cast<const uint4*>(xs + b * 32 * G_PITCH + kk * 16);
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -168,32 +179,76 @@ __global__ void __launch_bounds__(256) gemm16(GemmDesc d, const uint16_t* __rest
     __syncthreads();
   }
 
-  // epilogue: lane = pixel, 4 consecutive channels per register quad
+  // epilogue: lane = pixel, 4 consecutive channels per register quad.  A wave's 32-channel
+  // group never straddles an output phase (CO is a multiple of 32 or there is one phase), so the
+  // phase offset is scalar and the store offset is pixel base + a compile-time channel step.
 #pragma unroll
   for (int b = 0; b < PT; ++b) {
-    int prow = wp * 32 * PT + b * 32 + l31;
-    int img = row_img[prow];
+    const int prow = wp * 32 * PT + b * 32 + l31;
+    const int img = row_img[prow];
     if (img < 0) continue;
-    int my = row_my[prow], mx = row_mx[prow];
+    const int pix = ((img * d.OH + row_my[prow] * d.os + d.oy0) * d.OW + row_mx[prow] * d.os + d.ox0) * d.OC;
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
+      const int nb = n0 + wc * 64 + a * 32;  // wave-uniform
+      if (nb >= d.N) continue;
+      const int ph = nb / d.CO, co0 = nb - ph * d.CO;
+      const int py = ph / d.nphx, px = ph - py * d.nphx;
+      const int base = pix + (py * d.OW + px) * d.OC + co0 + 4 * h;
+      if (SPLITK) {
+        // one f32 slab per K slice, summed in slice order by splitk_finish16: reproducible bit for bit
+        float* pp = part + ((int64_t)blockIdx.z * d.M + (m0 + prow)) * d.Npad + nb + 4 * h;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        int n = n0 + wc * 64 + a * 32 + 8 * q + 4 * h;
-        if (n >= d.N) continue;
-        int ph = n / d.CO, co = n - ph * d.CO;
-        int py = ph / d.nphx, px = ph - py * d.nphx;
-        int oy = my * d.os + d.oy0 + py, ox = mx * d.os + d.ox0 + px;
-        float4 bv = *reinterpret_cast<const float4*>(bias + n);
-        float v0 = act16(acc[a][b][4 * q + 0] + bv.x, d.act), v1 = act16(acc[a][b][4 * q + 1] + bv.y, d.act);
-        float v2 = act16(acc[a][b][4 * q + 2] + bv.z, d.act), v3 = act16(acc[a][b][4 * q + 3] + bv.w, d.act);
-        uint2 o;
-        o.x = pack2<F16>(v0, v1);
-        o.y = pack2<F16>(v2, v3);
-        *reinterpret_cast<uint2*>(Y + (((int64_t)img * d.OH + oy) * d.OW + ox) * d.OC + co) = o;
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(pp + 8 * q) = make_float4(acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]);
+        continue;
+      }
+      const float* bp = bias + nb + 4 * h;
+      if (d.act == SRCFD_ACT_SWISH) {
+        f32x16 u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 bv = *reinterpret_cast<const float4*>(bp + 8 * q);
+          u[4 * q] = acc[a][b][4 * q] + bv.x; u[4 * q + 1] = acc[a][b][4 * q + 1] + bv.y;
+          u[4 * q + 2] = acc[a][b][4 * q + 2] + bv.z; u[4 * q + 3] = acc[a][b][4 * q + 3] + bv.w;
+        }
+        uint32_t o[8];
+        swish_pack16<F16>(u, o);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (nb + 8 * q + 4 * h < d.N) *reinterpret_cast<uint2*>(Y + (base + 8 * q)) = make_uint2(o[2 * q], o[2 * q + 1]);
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if (nb + 8 * q + 4 * h >= d.N) continue;
+          const float4 bv = *reinterpret_cast<const float4*>(bp + 8 * q);
+          uint2 o;
+          o.x = pack2<F16>(acc[a][b][4 * q] + bv.x, acc[a][b][4 * q + 1] + bv.y);
+          o.y = pack2<F16>(acc[a][b][4 * q + 2] + bv.z, acc[a][b][4 * q + 3] + bv.w);
+          *reinterpret_cast<uint2*>(Y + (base + 8 * q)) = o;
+        }
       }
     }
   }
+}
+
+// split-K epilogue for dense layers (1x1 row grid): y[m][n] = act(sum_z part[z][m][n] + bias[n])
+template <bool F16>
+__global__ void __launch_bounds__(256) splitk_finish16(const float* __restrict__ part, int nz, const float* __restrict__ bias,
+                                                        uint16_t* __restrict__ Y, int M, int N, int Npad, int OC, int act) {
+  int idx = blockIdx.x * 256 + threadIdx.x;
+  int n4 = N / 4;
+  if (idx >= M * n4) return;
+  int m = idx / n4, n = (idx - m * n4) * 4;
+  float4 v = *reinterpret_cast<const float4*>(bias + n);
+  for (int z = 0; z < nz; ++z) {
+    const float4 t = *reinterpret_cast<const float4*>(part + ((int64_t)z * M + m) * Npad + n);
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  }
+  uint2 o;
+  o.x = pack2<F16>(act16(v.x, act), act16(v.y, act));
+  o.y = pack2<F16>(act16(v.z, act), act16(v.w, act));
+  *reinterpret_cast<uint2*>(Y + (int64_t)m * OC + n) = o;
 }
 
 // ---------------------------------------------------------------------------
@@ -228,40 +283,6 @@ static_assert(T_LDS_BYTES <= 160 * 1024, "tail kernel LDS budget");
 
 __device__ __forceinline__ int ring_off(int Y, int X) { return (Y % T_RING_ROWS) * T_ROWP + (((X & 7) * T_PLANE + (X >> 3)) << 4); }
 __device__ __forceinline__ int l100_off(int a, int x, int chunk) { return (chunk * 212 + a * 106 + (x & 1) * 56 + (x >> 1)) << 4; }
-
-// 16 swish + pack, issued as four batches of 16 independent instructions (exp, add, rcp, mul):
-// hipcc interleaves the four dependent steps of neighbouring elements, and with only four waves per
-// SIMD the in-order issue then stalls on every step (measured 25 cycles per 64 activations); in
-// batch order no instruction waits on one issued fewer than 16 slots earlier (~14 cycles).
-template <bool F16>
-__device__ __forceinline__ void swish_pack16(const f32x16& dd, uint32_t (&o)[8], bool skip = false) {
-  if (skip) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) o[i] = pack2<F16>(dd[2 * i], dd[2 * i + 1]);
-    return;
-  }
-  float u[16], e[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) u[i] = dd[i];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) e[i] = __builtin_amdgcn_exp2f(-u[i]);  // builtin: hipcc pads the MFMA -> VALU read hazard itself
-#pragma unroll
-  for (int i = 0; i < 16; ++i) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(e[i]));
-#pragma unroll
-  for (int i = 0; i < 16; ++i) asm volatile("v_rcp_f32 %0, %0" : "+v"(e[i]));
-#pragma unroll
-  for (int i = 0; i < 16; ++i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(e[i]) : "v"(u[i]));
-#pragma unroll
-  for (int i = 0; i < 8; ++i) o[i] = pack2<F16>(e[2 * i], e[2 * i + 1]);
-}
-
-__device__ __forceinline__ f32x16 load_bias16(const char* base) {
-  f32x16 r;
-  const float4* p = reinterpret_cast<const float4*>(base);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { float4 v = p[i]; r[4 * i] = v.x; r[4 * i + 1] = v.y; r[4 * i + 2] = v.z; r[4 * i + 3] = v.w; }
-  return r;
-}
 
 // block-wide barrier that leaves global loads / stores in flight: only LDS traffic
 // has to be complete before the other waves may look at it
@@ -487,14 +508,43 @@ hipError_t launch_enc_conv1_16(bool f16, const float* x, const float* affine, co
   return hipGetLastError();
 }
 
-hipError_t launch_gemm16(bool f16, const GemmDesc& d, const uint16_t* X, const uint16_t* Wt, int Kpad, const float* bias, uint16_t* Y, hipStream_t s) {
+static int gemm16_lds(int bn) { return (G_BP + bn) * G_PITCH * 2 + 3 * G_BP * 4; }
+
+hipError_t launch_gemm16(bool f16, const GemmDesc& d, const uint16_t* X, const uint16_t* Wt, int Kpad, const float* bias, uint16_t* Y,
+                         float* part, int splits, hipStream_t s) {
   if (d.M == 0) return hipSuccess;
   const bool wide = d.Npad % 128 == 0;
-  dim3 grid((d.M + G_BP - 1) / G_BP, d.Npad / (wide ? 128 : 64));
-#define GO(F, B) hipLaunchKernelGGL((gemm16<F, B>), grid, dim3(256), 0, s, d, X, Wt, Kpad, bias, Y)
-  if (f16) { if (wide) GO(true, 128); else GO(true, 64); }
-  else { if (wide) GO(false, 128); else GO(false, 64); }
-#undef GO
+  const int bn = wide ? 128 : 64;
+  const bool sk = splits > 1 && part != nullptr;
+  int kslice = d.K;
+  if (sk) kslice = ((d.K / G_BK + splits - 1) / splits) * G_BK;
+  const int nz = sk ? (d.K + kslice - 1) / kslice : 1;
+  dim3 grid((d.M + G_BP - 1) / G_BP, d.Npad / bn, nz);
+  void (*fn)(GemmDesc, const uint16_t*, const uint16_t*, int, const float*, uint16_t*, float*, int) = nullptr;
+  int slot = (f16 ? 4 : 0) + (wide ? 2 : 0) + (sk ? 1 : 0);
+  switch (slot) {
+    case 0: fn = gemm16<false, 64, false>; break;
+    case 1: fn = gemm16<false, 64, true>; break;
+    case 2: fn = gemm16<false, 128, false>; break;
+    case 3: fn = gemm16<false, 128, true>; break;
+    case 4: fn = gemm16<true, 64, false>; break;
+    case 5: fn = gemm16<true, 64, true>; break;
+    case 6: fn = gemm16<true, 128, false>; break;
+    default: fn = gemm16<true, 128, true>; break;
+  }
+  static bool attr_done[8] = {};
+  const int lds = gemm16_lds(bn);
+  if (!attr_done[slot]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    attr_done[slot] = true;
+  }
+  hipLaunchKernelGGL(fn, grid, dim3(256), lds, s, d, X, Wt, Kpad, bias, Y, part, kslice);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || !sk) return e;
+  const int total = d.M * (d.N / 4);
+  if (f16) hipLaunchKernelGGL(splitk_finish16<true>, dim3((total + 255) / 256), dim3(256), 0, s, part, nz, bias, Y, d.M, d.N, d.Npad, d.OC, d.act);
+  else hipLaunchKernelGGL(splitk_finish16<false>, dim3((total + 255) / 256), dim3(256), 0, s, part, nz, bias, Y, d.M, d.N, d.Npad, d.OC, d.act);
   return hipGetLastError();
 }
 
