@@ -348,82 +348,94 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
   }
 
   const bool ab_sw = p.ablate & 1;
-  for (int sample = blockIdx.x; sample < p.n; sample += gridDim.x) {
-    float o_mean = 0.f, o_std = 1.f;
-    if (p.aff_out) {
-      // wave-uniform: park them in SGPRs now, so no later use waits on vmcnt (which would also
-      // drain this wave's in-flight output stores and input prefetch)
-      o_mean = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.aff_out[2 * sample])));
-      o_std = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.aff_out[2 * sample + 1])));
-    }
-    unsigned bad_count = 0;
+  // This workgroup's samples k = 0..K-1 (ids blockIdx.x + k*gridDim.x) are treated as one tall image of
+  // 400*K rows: strip g = 50*k + s.  Round r runs A(g=r), BC(g=r-1), D(g=r-2), so the pipeline never
+  // drains between samples; D(g) covers rows 8g-1 .. 8g+6 of the tall image, and its first row pair at a
+  // sample seam (last row of sample k-1, first row of sample k) is evaluated once per side of the seam.
+  const int K = ((int)blockIdx.x < p.n) ? (p.n - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  const int G = 50 * K;
+  float o_mean = 0.f, o_std = 1.f, o_mean_prev = 0.f, o_std_prev = 1.f;  // de-standardisation of D's sample / the one before
+  unsigned bad_count = 0;
 
-    for (int rho = 0; rho <= 52; ++rho) {
-      // ---------------- BC: ConvT#3 + ConvT#4 on 32 pixels of the 100-level ----------------
-      auto do_bc = [&]() {
-        if (!(bc_item >= 0 && rho >= 1 && rho <= 50 && !(p.ablate & 8))) return;
-        const int s = rho - 1, t = bc_item >> 1, m3 = bc_item & 1;
-        int idx = 32 * t + l31;
-        const bool valid = idx < 200;
-        if (!valid) idx = 199;
-        const int a = idx >= 100 ? 1 : 0, x100 = idx - 100 * a;
-        const char* src = l100 + (s & 1) * T_L100_BUF;
-        uint4 b0 = *reinterpret_cast<const uint4*>(src + l100_off(a, x100, h)), b1 = *reinterpret_cast<const uint4*>(src + l100_off(a, x100, 2 + h));
-        f32x16 acc3 = load_bias16(cst + TC_OFF_B3 + h * 64);
-        acc3 = mfma32<F16>(w3_f[(m3 * 2 + 0) * 64 + lane], b0, acc3);
-        acc3 = mfma32<F16>(w3_f[(m3 * 2 + 1) * 64 + lane], b1, acc3);
-        uint32_t f3[8];
-        swish_pack16<F16>(acc3, f3, ab_sw);
-        // ring address = row slot (uniform base + small per-lane offset) + swizzled granule of x = 4*x100 + c
-        const int rbase = (8 * s) % T_RING_ROWS;
-        const int rowv = rbase + 4 * a;
-        char* wbase = ring + (((x100 & 1) * (4 * T_PLANE) + (x100 >> 1)) << 4) + 8 * h;
-        const f32x16 bias4 = load_bias16(cst + TC_OFF_B4 + h * 64);
+  for (int r = 0; r <= G + 2 && K > 0; ++r) {
+    // ---------------- BC: ConvT#3 + ConvT#4 on 32 pixels of the 100-level ----------------
+    auto do_bc = [&]() {
+      const int g = r - 1;
+      if (!(bc_item >= 0 && g >= 0 && g < G && !(p.ablate & 8))) return;
+      const int t = bc_item >> 1, m3 = bc_item & 1;
+      int idx = 32 * t + l31;
+      const bool valid = idx < 200;
+      if (!valid) idx = 199;
+      const int a = idx >= 100 ? 1 : 0, x100 = idx - 100 * a;
+      const char* src = l100 + (g & 1) * T_L100_BUF;
+      uint4 b0 = *reinterpret_cast<const uint4*>(src + l100_off(a, x100, h)), b1 = *reinterpret_cast<const uint4*>(src + l100_off(a, x100, 2 + h));
+      f32x16 acc3 = load_bias16(cst + TC_OFF_B3 + h * 64);
+      acc3 = mfma32<F16>(w3_f[(m3 * 2 + 0) * 64 + lane], b0, acc3);
+      acc3 = mfma32<F16>(w3_f[(m3 * 2 + 1) * 64 + lane], b1, acc3);
+      uint32_t f3[8];
+      swish_pack16<F16>(acc3, f3, ab_sw);
+      // ring address = row slot (uniform base + small per-lane offset) + swizzled granule of x = 4*x100 + c
+      const int rbase = (8 * g) % T_RING_ROWS;  // tall-image row 8g
+      const int rowv = rbase + 4 * a;
+      char* wbase = ring + (((x100 & 1) * (4 * T_PLANE) + (x100 >> 1)) << 4) + 8 * h;
+      const f32x16 bias4 = load_bias16(cst + TC_OFF_B4 + h * 64);
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-          const int tap3 = 2 * m3 + tt, a3 = tap3 >> 1, b3 = tap3 & 1;
-          uint4 bf = make_uint4(f3[4 * tt], f3[4 * tt + 1], f3[4 * tt + 2], f3[4 * tt + 3]);
-          f32x16 acc4 = mfma32<F16>(w4, bf, bias4);
-          uint32_t f4[8];
-          swish_pack16<F16>(acc4, f4, ab_sw);
-          if (valid) {
+      for (int tt = 0; tt < 2; ++tt) {
+        const int tap3 = 2 * m3 + tt, a3 = tap3 >> 1, b3 = tap3 & 1;
+        uint4 bf = make_uint4(f3[4 * tt], f3[4 * tt + 1], f3[4 * tt + 2], f3[4 * tt + 3]);
+        f32x16 acc4 = mfma32<F16>(w4, bf, bias4);
+        uint32_t f4[8];
+        swish_pack16<F16>(acc4, f4, ab_sw);
+        if (valid) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              int rr = rowv + 2 * a3 + (q >> 1);
-              rr = rr >= T_RING_ROWS ? rr - T_RING_ROWS : rr;
-              *reinterpret_cast<uint2*>(wbase + rr * T_ROWP + (2 * b3 + (q & 1)) * (T_PLANE * 16)) = make_uint2(f4[2 * q], f4[2 * q + 1]);
-            }
+          for (int q = 0; q < 4; ++q) {
+            int rr = rowv + 2 * a3 + (q >> 1);
+            rr = rr >= T_RING_ROWS ? rr - T_RING_ROWS : rr;
+            *reinterpret_cast<uint2*>(wbase + rr * T_ROWP + (2 * b3 + (q & 1)) * (T_PLANE * 16)) = make_uint2(f4[2 * q], f4[2 * q + 1]);
           }
         }
-      };
+      }
+    };
 
-      // ---------------- D: output conv of strip rho-2, rows 8s-1 .. 8s+6 ----------------
-      // One item = one output row pair (rp, wave-uniform) x 16 tiles of 2x8 pixels, so row
-      // slots / validity live in SGPRs and each lane only adds its own column offset.
-      const bool d_on = rho >= 2 && !(p.ablate & 2);
-      {
-        auto do_d = [&](const int item) {  // called (not looped) so no conservative vmcnt(0) lands in front of it
-          const int s = rho - 2, rp = item >> 2, j4 = item & 3;
-          const int kg = lane >> 4;
-          int tx = 16 * j4 + d_tsel;
-          tx = tx < 50 ? tx : 49;
-          const int Ya = 8 * s - 2 + 2 * rp;  // first window row (dy = 0)
-          const int sa = (8 * s + 16 + 2 * rp) % T_RING_ROWS;
-          const int Y0 = Ya + d_dy, Y1 = Y0 + 2;
-          int s0 = sa + d_dy, s1 = s0 + 2;
-          s0 = s0 >= T_RING_ROWS ? s0 - T_RING_ROWS : s0;
-          s1 = s1 >= T_RING_ROWS ? s1 - T_RING_ROWS : s1;
-          const int r0 = T_OFF_RING + s0 * T_ROWP + tx * 16, r1 = T_OFF_RING + s1 * T_ROWP + tx * 16;
-          const bool okf = !(d_dx == 0 && tx == 0), okl = !(d_dx == 1 && tx == 49);
-          const bool interior = s >= 1 && s <= 49;  // wave-uniform: only the image's left/right edge can be outside
-          const bool ok0 = interior || (unsigned)Y0 < 400u, ok1 = interior || (unsigned)Y1 < 400u;
+    // ---------------- D: output conv of strip g = r-2: tall-image rows 8g-1 .. 8g+6 ----------------
+    // One item = one output row pair (rp, wave-uniform) x 16 tiles of 2x8 pixels, so row slots and
+    // validity live in SGPRs and each lane only adds its own column offset.
+    const int gd = r - 2;
+    const bool d_on = gd >= 0 && !(p.ablate & 2);
+    const int kd = gd >= 0 ? gd / 50 : 0, sd = gd - 50 * kd;
+    const int sample_d = (int)blockIdx.x + kd * (int)gridDim.x;  // == p.n-range only while gd < G
+    if (d_on && sd == 0 && p.aff_out) {  // entering sample kd: rotate the de-standardisation scalars (SGPRs)
+      o_mean_prev = o_mean; o_std_prev = o_std;
+      if (gd < G) {
+        o_mean = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.aff_out[2 * sample_d])));
+        o_std = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.aff_out[2 * sample_d + 1])));
+      }
+    }
+    {
+      auto do_d = [&](const int item) {  // called (not looped) so no conservative vmcnt(0) lands in front of it
+        const int rp = item >> 2, j4 = item & 3;
+        const bool seam = sd == 0 && rp == 0;          // row pair = (row 399 of sample kd-1, row 0 of sample kd)
+        if (gd == G && !seam) return;                  // flush round: only the last sample's row 399 is left
+        const int kg = lane >> 4;
+        int tx = 16 * j4 + d_tsel;
+        tx = tx < 50 ? tx : 49;
+        const int sa = (8 * gd + 16 + 2 * rp) % T_RING_ROWS;  // slot of the first window row (tall row 8g-2+2rp)
+        int s0 = sa + d_dy, s1 = s0 + 2;
+        s0 = s0 >= T_RING_ROWS ? s0 - T_RING_ROWS : s0;
+        s1 = s1 >= T_RING_ROWS ? s1 - T_RING_ROWS : s1;
+        const int r0 = T_OFF_RING + s0 * T_ROWP + tx * 16, r1 = T_OFF_RING + s1 * T_ROWP + tx * 16;
+        const bool okf = !(d_dx == 0 && tx == 0), okl = !(d_dx == 1 && tx == 49);
+        const int oy = (lane >> 3) & 1, ox = lane & 7;
+        const int txo = 16 * j4 + kg;
+        // window rows 0,1 (k-steps 0-4) / 2,3 (k-steps 5-9); side 0 keeps rows 0,1 (sample kd-1), side 1 rows 2,3
+        auto conv = [&](const bool keep01, const bool keep23) {
           f32x4 acc = {conv_bias, conv_bias, conv_bias, conv_bias};
 #pragma unroll
           for (int half = 0; half < 2; ++half) {  // two batches of five k-steps keep the live operand set at 40 VGPRs
             uint4 av[5], wv[5];
 #pragma unroll
             for (int cp = 0; cp < 5; ++cp) {
-              bool ok = half ? ok1 : ok0;
+              bool ok = half ? keep23 : keep01;
               if (cp == 0) ok = ok && okf;
               if (cp == 4) ok = ok && okl;
               const int off = ok ? (half ? r1 : r0) + d_xo[cp] : T_OFF_ZERO;
@@ -434,67 +446,74 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
             for (int cp = 0; cp < 5; ++cp) acc = mfma16<F16>(av[cp], wv[cp], acc);
             __builtin_amdgcn_sched_barrier(0);
           }
-          // accumulator register r of lane group kg holds tile 16*j4 + 4r + kg, pixel (oy,ox) = lane & 15
-          const int oy = (lane >> 3) & 1, ox = lane & 7;
-          const int Y = 8 * s - 1 + 2 * rp + oy;
-          const int txo = 16 * j4 + kg;
-          if ((unsigned)Y < 400u) {
-            const size_t o0 = ((size_t)sample * 400 + Y) * 400 + 8 * txo + ox;
+          return acc;
+        };
+        // accumulator register rr of lane group kg holds tile 16*j4 + 4rr + kg, pixel (oy,ox) = lane & 15
+        auto store = [&](const f32x4& acc, const int smp, const int Y, const float mean, const float sdv, const bool lane_on) {
+          if (!lane_on) return;
+          const size_t o0 = ((size_t)smp * 400 + Y) * 400 + 8 * txo + ox;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              if (txo + 4 * r >= 50) continue;
-              float v = acc[r];
-              if (p.aff_out) v = __fadd_rn(__fmul_rn(v, o_std), o_mean);
-              if (p.nan_guard && !(fabsf(v) <= 3.402823466e38f)) { v = 0.f; ++bad_count; }
-              const size_t o = o0 + 32 * r;
-              if (OUT == 0) reinterpret_cast<float*>(p.out)[o] = v;
-              else if (OUT == 1) reinterpret_cast<uint16_t*>(p.out)[o] = (uint16_t)(pack2<false>(v, 0.f) & 0xffff);
-              else reinterpret_cast<uint16_t*>(p.out)[o] = (uint16_t)(pack2<true>(v, 0.f) & 0xffff);
-            }
+          for (int rr = 0; rr < 4; ++rr) {
+            if (txo + 4 * rr >= 50) continue;
+            float v = acc[rr];
+            if (p.aff_out) v = __fadd_rn(__fmul_rn(v, sdv), mean);
+            if (p.nan_guard && !(fabsf(v) <= 3.402823466e38f)) { v = 0.f; ++bad_count; }
+            const size_t o = o0 + 32 * rr;
+            if (OUT == 0) reinterpret_cast<float*>(p.out)[o] = v;
+            else if (OUT == 1) reinterpret_cast<uint16_t*>(p.out)[o] = (uint16_t)(pack2<false>(v, 0.f) & 0xffff);
+            else reinterpret_cast<uint16_t*>(p.out)[o] = (uint16_t)(pack2<true>(v, 0.f) & 0xffff);
           }
         };
-        // stagger: the BC-only-plus-D waves do their latency-bound D items first, so their VALU-heavy
-        // BC items overlap the tail (A items) of the waves that started with BC
-        if (wave >= 8) {
-          if (d_on && d_cnt >= 1) do_d(d_first);
-          if (d_on && d_cnt >= 2) do_d(d_first + 1);
-        }
-        do_bc();
-        if (wave < 8) {
-          if (d_on && d_cnt >= 1) do_d(d_first);
-          if (d_on && d_cnt >= 2) do_d(d_first + 1);
-        }
-      }
-
-      // ---------------- A: ConvT#2 for strip rho (input prefetched last round), then prefetch ----------------
-      if (hasA && rho <= 49 && !(p.ablate & 4)) {
-        const int s = rho;
-        f32x16 acc = load_bias16(cst + TC_OFF_B2 + h * 64);
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) acc = mfma32<F16>(wa[kk], xb[kk], acc);
-        // next strip of this sample, or the first strip of this workgroup's next sample
-        {
-          int ns = sample, nr = rho + 1;
-          if (nr > 49) { ns = sample + gridDim.x; nr = 0; }
-          if (ns < p.n) {
-            const uint16_t* src = p.in + (((size_t)ns * 50 + nr) * 50 + a_pxc) * 64 + 8 * h;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) xb[kk] = *reinterpret_cast<const uint4*>(src + 16 * kk);
+        if (!seam) {
+          const f32x4 acc = conv(true, true);
+          store(acc, sample_d, 8 * sd - 1 + 2 * rp + oy, o_mean, o_std, true);
+        } else {
+          if (kd > 0) {      // last row of the previous sample: rows 398,399 | zeros
+            const f32x4 acc = conv(true, false);
+            store(acc, sample_d - (int)gridDim.x, 399, o_mean_prev, o_std_prev, oy == 0);
+          }
+          if (gd < G) {      // first row of this sample: zeros | rows 0,1
+            const f32x4 acc = conv(false, true);
+            store(acc, sample_d, 0, o_mean, o_std, oy == 1);
           }
         }
-        uint32_t f2[8];
-        swish_pack16<F16>(acc, f2, ab_sw);
-        if (a_valid) {
-          const int a = a_mt >> 1, x100 = 2 * a_px + (a_mt & 1);
-          char* dst = l100 + (s & 1) * T_L100_BUF + 8 * h;
-#pragma unroll
-          for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(dst + l100_off(a, x100, q)) = make_uint2(f2[2 * q], f2[2 * q + 1]);
-        }
+      };
+      // stagger: the BC-only-plus-D waves do their latency-bound D items first, so their VALU-heavy
+      // BC items overlap the tail (A items) of the waves that started with BC
+      if (wave >= 8) {
+        if (d_on && d_cnt >= 1) do_d(d_first);
+        if (d_on && d_cnt >= 2) do_d(d_first + 1);
       }
-      lds_barrier();
+      do_bc();
+      if (wave < 8) {
+        if (d_on && d_cnt >= 1) do_d(d_first);
+        if (d_on && d_cnt >= 2) do_d(d_first + 1);
+      }
     }
-    if (p.nan_guard && p.nonfinite && bad_count) atomicAdd(p.nonfinite, (unsigned long long)bad_count);
+
+    // ---------------- A: ConvT#2 for strip g = r (input prefetched last round), then prefetch g+1 ----------------
+    if (hasA && r < G && !(p.ablate & 4)) {
+      f32x16 acc = load_bias16(cst + TC_OFF_B2 + h * 64);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) acc = mfma32<F16>(wa[kk], xb[kk], acc);
+      if (r + 1 < G) {
+        const int kn = (r + 1) / 50, sn = (r + 1) - 50 * kn;
+        const uint16_t* src = p.in + (((size_t)((int)blockIdx.x + kn * (int)gridDim.x) * 50 + sn) * 50 + a_pxc) * 64 + 8 * h;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) xb[kk] = *reinterpret_cast<const uint4*>(src + 16 * kk);
+      }
+      uint32_t f2[8];
+      swish_pack16<F16>(acc, f2, ab_sw);
+      if (a_valid) {
+        const int a = a_mt >> 1, x100 = 2 * a_px + (a_mt & 1);
+        char* dst = l100 + (r & 1) * T_L100_BUF + 8 * h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(dst + l100_off(a, x100, q)) = make_uint2(f2[2 * q], f2[2 * q + 1]);
+      }
+    }
+    lds_barrier();
   }
+  if (p.nan_guard && p.nonfinite && bad_count) atomicAdd(p.nonfinite, (unsigned long long)bad_count);
 }
 
 // ---------------------------------------------------------------------------

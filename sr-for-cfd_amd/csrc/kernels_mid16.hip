@@ -20,44 +20,57 @@
 
 namespace srcfd {
 
-constexpr int M_PITCH = 72;          // LDS row pitch in elements (144 B)
-constexpr int M_PATCH = 176;         // patch rows; row M_PATCH is all zero (out-of-image taps)
-constexpr int M_OFF_W = (M_PATCH + 1) * M_PITCH * 2;           // bytes
-constexpr int M_OFF_META = M_OFF_W + 128 * M_PITCH * 2;
-constexpr int M_LDS = M_OFF_META + 3 * 128 * 4;
-static_assert(M_OFF_META >= 32768, "ConvT#1 operand half (32 KB) is staged over the patch + weight tiles");
+constexpr int M_PITCH = 72;  // LDS row pitch in elements (144 B)
 
-template <bool F16>
-__global__ void __launch_bounds__(256, 3) mid16(MidParams p) {
+// NW waves per workgroup, each owning 32 output pixels x 128 channels.  The weight tile (16 KB per
+// stage) is shared by all NW waves, so bytes pulled through L2 per output pixel fall as 1/NW:
+// with 4 waves this kernel sat at ~17 GB/s per CU of operand traffic (the per-CU load rate), not on the MFMAs.
+template <int NW> struct MidCfg {
+  static constexpr int PX = 32 * NW;                    // output pixels per workgroup
+  static constexpr int PATCH = ((PX + 12) / 13 + 2) * 12 + 16;  // input-pixel slab bound (+ slack), rows
+  static constexpr int OFF_W = (PATCH + 1) * M_PITCH * 2;       // bytes; row PATCH is all zero
+  static constexpr int MAIN_END = OFF_W + 128 * M_PITCH * 2;
+  static constexpr int T1_END = 32768 + NW * 32 * 144;          // ConvT#1 stage: operand half + per-wave store tiles
+  static constexpr int OFF_META = MAIN_END > T1_END ? MAIN_END : T1_END;
+  static constexpr int LDS = OFF_META + 3 * PX * 4;
+  static constexpr int NTHR = 64 * NW;
+  static constexpr int WCH = 1024 / NTHR;               // weight-tile 16-byte chunks per thread
+  static constexpr int PCH = (PATCH * 8 + NTHR - 1) / NTHR;  // patch chunks per thread
+};
+
+template <bool F16, int NW>
+__global__ void __launch_bounds__(64 * NW) mid16(MidParams p) {
+  using C = MidCfg<NW>;
+  static_assert(C::OFF_META >= 32768 + NW * 32 * 144, "ConvT#1 operand half (32 KB) + per-wave store tiles are staged over the patch + weight tiles");
   extern __shared__ __attribute__((aligned(16))) char msm[];
   uint16_t* Ps = reinterpret_cast<uint16_t*>(msm);
-  uint16_t* Ws = reinterpret_cast<uint16_t*>(msm + M_OFF_W);
-  int* row_img = reinterpret_cast<int*>(msm + M_OFF_META);
-  int* row_my = row_img + 128;
-  int* row_mx = row_my + 128;
+  uint16_t* Ws = reinterpret_cast<uint16_t*>(msm + C::OFF_W);
+  int* row_img = reinterpret_cast<int*>(msm + C::OFF_META);
+  int* row_my = row_img + C::PX;
+  int* row_mx = row_my + C::PX;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
   const int phase = blockIdx.y, py = phase >> 1, px = phase & 1;
   const int TY = py ? 1 : 2, TX = px ? 1 : 2, NT = TY * TX;
   const int MH = py ? 12 : 13, MW = px ? 12 : 13, per = MH * MW;
-  const int M = p.n * per, m0 = blockIdx.x * 128;
+  const int M = p.n * per, m0 = blockIdx.x * C::PX;
   if (m0 >= M) return;
   const uint16_t* Wt = p.w0[phase];
   const int Kp = p.kpad[phase];
 
-  if (tid < 128) {
+  if (tid < C::PX) {
     int m = m0 + tid, img = -1, my = 0, mx = 0;
     if (m < M) { img = m / per; int r = m - img * per; my = r / MW; mx = r - my * MW; }
     row_img[tid] = img; row_my[tid] = my; row_mx[tid] = mx;
   }
-  if (tid < M_PITCH / 2) reinterpret_cast<uint32_t*>(Ps + M_PATCH * M_PITCH)[tid] = 0;
+  if (tid < M_PITCH / 2) reinterpret_cast<uint32_t*>(Ps + C::PATCH * M_PITCH)[tid] = 0;
   __syncthreads();
 
   // contiguous slab of input pixels (tensor index img*144 + iy*12 + ix) this workgroup touches
-  const int mlast = min(m0 + 127, M - 1) - m0;
+  const int mlast = min(m0 + C::PX - 1, M - 1) - m0;
   const int lo = row_img[0] * 144 + max(row_my[0] - 1, 0) * 12;
   const int hi = row_img[mlast] * 144 + min(row_my[mlast], 11) * 12 + 11;
-  const int NP = hi - lo + 1;  // <= M_PATCH by construction (<= 13 input rows of 12 + one row of slack)
+  const int NP = min(hi - lo + 1, C::PATCH);  // <= PATCH by construction; the clamp only guards LDS
 
   // this lane's pixel and the patch row each tap reads
   const int prow = wave * 32 + l31;
@@ -67,33 +80,35 @@ __global__ void __launch_bounds__(256, 3) mid16(MidParams p) {
   for (int t = 0; t < 4; ++t) {
     const int ty = t / TX, tx = t - ty * TX;  // only t < NT is used
     const int iy = my - ty, ix = mx - tx;
-    const bool ok = img >= 0 && t < NT && (unsigned)iy < 12u && (unsigned)ix < 12u;
-    trow[t] = (ok ? img * 144 + iy * 12 + ix - lo : M_PATCH) * M_PITCH + h * 8;
+    int r = img * 144 + iy * 12 + ix - lo;
+    const bool ok = img >= 0 && t < NT && (unsigned)iy < 12u && (unsigned)ix < 12u && (unsigned)r < (unsigned)C::PATCH;
+    trow[t] = (ok ? r : C::PATCH) * M_PITCH + h * 8;
   }
 
-  // staging roles: 16-byte column c8 of rows xrow + 32j
+  // staging roles: 16-byte column c8 of rows xrow + (NTHR/8)*j
+  constexpr int RSTEP = C::NTHR / 8;
   const int xrow = tid >> 3, c8 = tid & 7;
-  uint4 wr[4], pr[6];
+  uint4 wr[C::WCH], pr[C::PCH];
   auto g2r_w = [&](int t, int c) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wr[j] = *reinterpret_cast<const uint4*>(Wt + (xrow + 32 * j) * Kp + t * 256 + c * 64 + c8 * 8);
+    for (int j = 0; j < C::WCH; ++j) wr[j] = *reinterpret_cast<const uint4*>(Wt + (xrow + RSTEP * j) * Kp + t * 256 + c * 64 + c8 * 8);
   };
   auto g2r_p = [&](int c) {
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const int r = xrow + 32 * j;
+    for (int j = 0; j < C::PCH; ++j) {
+      const int r = xrow + RSTEP * j;
       pr[j] = r < NP ? *reinterpret_cast<const uint4*>(p.in + (size_t)(lo + r) * 256 + c * 64 + c8 * 8) : make_uint4(0, 0, 0, 0);
     }
   };
   auto r2l_w = [&]() {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<uint4*>(Ws + (xrow + 32 * j) * M_PITCH + c8 * 8) = wr[j];
+    for (int j = 0; j < C::WCH; ++j) *reinterpret_cast<uint4*>(Ws + (xrow + RSTEP * j) * M_PITCH + c8 * 8) = wr[j];
   };
   auto r2l_p = [&]() {
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const int r = xrow + 32 * j;
-      if (r < M_PATCH) *reinterpret_cast<uint4*>(Ps + r * M_PITCH + c8 * 8) = pr[j];
+    for (int j = 0; j < C::PCH; ++j) {
+      const int r = xrow + RSTEP * j;
+      if (r < C::PATCH) *reinterpret_cast<uint4*>(Ps + r * M_PITCH + c8 * 8) = pr[j];
     }
   };
 
@@ -111,12 +126,13 @@ __global__ void __launch_bounds__(256, 3) mid16(MidParams p) {
     r2l_w();
     if (t == 0) r2l_p();
     __syncthreads();
-    if (s + 1 < NS) {
+    if (s + 1 < NS && !(p.ablate & 4)) {
       const int c1 = (s + 1) / NT, t1 = (s + 1) - c1 * NT;
       g2r_w(t1, c1);
       if (t1 == 0) g2r_p(c1);
     }
     const uint16_t* bsrc = Ps + trow[t];
+    if (!(p.ablate & 1))
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const uint4 bf = *reinterpret_cast<const uint4*>(bsrc + kk * 16);
@@ -135,52 +151,74 @@ __global__ void __launch_bounds__(256, 3) mid16(MidParams p) {
   for (int mt = 0; mt < 4; ++mt) swish_pack16<F16>(acc[mt], fb[mt]);
 
   // ---- ConvT#1: 8 tiles of 32 rows (tap = j8 >> 1, channels 32*(j8&1)..+31), K = 128 = 8 k-steps.
-  // Its 64 KB of A operands go through the (now free) LDS in two halves, shared by the four waves.
+  // Its 64 KB of A operands go through the (now free) LDS in two halves, shared by all waves.
+  // Each tap's 32 pixels x 64 channels are transposed through a wave-private LDS tile so that the
+  // global stores are whole 128-byte pixel rows (16 B per lane, 8 lanes per pixel) instead of
+  // 8-byte pieces 512 B apart -- the scattered form was store-issue bound (~0.06 ms per batch).
   const uint4* w1 = reinterpret_cast<const uint4*>(p.w1f);
   uint4* w1s = reinterpret_cast<uint4*>(msm);
+  char* stage = msm + 32768 + wave * (32 * 144);  // [32 pixels][144 B]
   const int Y = 2 * my + py, X = 2 * mx + px;  // 25x25-level pixel
+  const int obase = img >= 0 ? ((img * 50 + 2 * Y) * 50 + 2 * X) * 64 : -1;  // element offset of tap (0,0)
+  if (!(p.ablate & 2))
 #pragma unroll 1
   for (int half = 0; half < 2; ++half) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) w1s[tid + 256 * j] = w1[half * 2048 + tid + 256 * j];
+    for (int j = 0; j < 2048 / C::NTHR; ++j) w1s[tid + C::NTHR * j] = w1[half * 2048 + tid + C::NTHR * j];
     __syncthreads();
 #pragma unroll 1
-    for (int jj = 0; jj < 4; ++jj) {
-      const int j8 = half * 4 + jj;
-      f32x16 a1 = load_bias16(reinterpret_cast<const char*>(p.b1f) + ((j8 & 1) * 2 + h) * 64);
+    for (int tl = 0; tl < 2; ++tl) {
+      const int tap = 2 * half + tl;
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const uint4 wf = w1s[(jj * 8 + s) * 64 + lane];
-        const uint4 bf = make_uint4(fb[s >> 1][4 * (s & 1)], fb[s >> 1][4 * (s & 1) + 1], fb[s >> 1][4 * (s & 1) + 2], fb[s >> 1][4 * (s & 1) + 3]);
-        a1 = mfma32<F16>(wf, bf, a1);
+      for (int jh = 0; jh < 2; ++jh) {
+        const int jj = 2 * tl + jh;
+        f32x16 a1 = load_bias16(reinterpret_cast<const char*>(p.b1f) + (jh * 2 + h) * 64);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+          const uint4 wf = w1s[(jj * 8 + s) * 64 + lane];
+          const uint4 bf = make_uint4(fb[s >> 1][4 * (s & 1)], fb[s >> 1][4 * (s & 1) + 1], fb[s >> 1][4 * (s & 1) + 2], fb[s >> 1][4 * (s & 1) + 3]);
+          a1 = mfma32<F16>(wf, bf, a1);
+        }
+        uint32_t o[8];
+        swish_pack16<F16>(a1, o);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<uint2*>(stage + l31 * 144 + 64 * jh + 16 * q + 8 * h) = make_uint2(o[2 * q], o[2 * q + 1]);
       }
-      uint32_t o[8];
-      swish_pack16<F16>(a1, o);
-      if (img >= 0) {
-        const int tap = j8 >> 1, Yo = 2 * Y + (tap >> 1), Xo = 2 * X + (tap & 1);
-        uint16_t* dst = p.out + ((size_t)(img * 50 + Yo) * 50 + Xo) * 64 + 32 * (j8 & 1) + 4 * h;
+      // coalesced write-out of this tap: lane -> (pixel = lane/8 + 8r, 16-byte chunk = lane%8)
+      const int toff = ((tap >> 1) * 50 + (tap & 1)) * 64;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(dst + 8 * q) = make_uint2(o[2 * q], o[2 * q + 1]);
+      for (int r = 0; r < 4; ++r) {
+        const int pix = (lane >> 3) + 8 * r;
+        const int ob = __shfl(obase, pix, 64);
+        const uint4 v = *reinterpret_cast<const uint4*>(stage + pix * 144 + (lane & 7) * 16);
+        if (ob >= 0) *reinterpret_cast<uint4*>(p.out + ob + toff + (lane & 7) * 8) = v;
       }
     }
     __syncthreads();
   }
 }
 
-int mid16_lds_bytes() { return M_LDS; }
-
-hipError_t launch_mid16(bool f16, const MidParams& p, hipStream_t s) {
-  if (p.n == 0) return hipSuccess;
-  static bool attr_done[2] = {};
-  void (*fn)(MidParams) = f16 ? mid16<true> : mid16<false>;
-  if (!attr_done[f16 ? 1 : 0]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, M_LDS);
+template <bool F16, int NW>
+static hipError_t launch_mid16_nw(const MidParams& p, hipStream_t s) {
+  using C = MidCfg<NW>;
+  static bool attr_done = false;
+  void (*fn)(MidParams) = mid16<F16, NW>;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
     if (e != hipSuccess) return e;
-    attr_done[f16 ? 1 : 0] = true;
+    attr_done = true;
   }
-  const int blocks = (p.n * 169 + 127) / 128;  // the largest phase (13x13 pixels per sample)
-  hipLaunchKernelGGL(fn, dim3(blocks, 4), dim3(256), M_LDS, s, p);
+  const int blocks = (p.n * 169 + C::PX - 1) / C::PX;  // the largest phase (13x13 pixels per sample)
+  hipLaunchKernelGGL(fn, dim3(blocks, 4), dim3(C::NTHR), C::LDS, s, p);
   return hipGetLastError();
+}
+
+hipError_t launch_mid16(bool f16, const MidParams& p, int waves, hipStream_t s) {
+  if (p.n == 0) return hipSuccess;
+  if (waves == 4) return f16 ? launch_mid16_nw<true, 4>(p, s) : launch_mid16_nw<false, 4>(p, s);
+  if (waves == 16) return f16 ? launch_mid16_nw<true, 16>(p, s) : launch_mid16_nw<false, 16>(p, s);
+  return f16 ? launch_mid16_nw<true, 8>(p, s) : launch_mid16_nw<false, 8>(p, s);
 }
 
 }  // namespace srcfd

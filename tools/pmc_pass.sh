@@ -3,7 +3,7 @@
 TAG=$1; CTRS=$2; shift 2
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/pmc_$TAG; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $OUT/run.log 2>&1
+timeout -k 10 150 rocprofv3 --pmc $CTRS --kernel-trace --output-format csv -d $OUT -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $OUT/run.log 2>&1
 python3 - <<PY
 import csv, glob, collections
 for f in glob.glob("$OUT/*/*_counter_collection.csv"):
