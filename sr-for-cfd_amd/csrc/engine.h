@@ -55,6 +55,21 @@ struct Model {
 
   FusedState* fused = nullptr;
 
+  // hipGraph replay of the fused 16-bit pipeline: a call whose arguments equal the previous call's is
+  // captured once on a private stream and replayed afterwards (removes ~8 launch gaps per batch)
+  struct GraphKey {
+    const void* x = nullptr; const void* y = nullptr; const float* ain = nullptr; const float* aout = nullptr;
+    unsigned long long* nf = nullptr; int n = -1, out_dtype = 0, flags = 0, precision = 0;
+    bool operator==(const GraphKey& o) const {
+      return x == o.x && y == o.y && ain == o.ain && aout == o.aout && nf == o.nf && n == o.n && out_dtype == o.out_dtype &&
+             flags == o.flags && precision == o.precision;
+    }
+  };
+  GraphKey graph_key, last_key;
+  hipGraphExec_t graph_exec = nullptr;
+  hipStream_t graph_stream = nullptr;
+  void drop_graph();
+
   ~Model();
   int init_device();
   void free_workspace();

@@ -27,7 +27,9 @@ constexpr int M_PITCH = 72;  // LDS row pitch in elements (144 B)
 // with 4 waves this kernel sat at ~17 GB/s per CU of operand traffic (the per-CU load rate), not on the MFMAs.
 template <int NW> struct MidCfg {
   static constexpr int PX = 32 * NW;                    // output pixels per workgroup
-  static constexpr int PATCH = ((PX + 12) / 13 + 2) * 12 + 16;  // input-pixel slab bound (+ slack), rows
+  // input-pixel slab bound, rows: a 12-wide phase packs PX pixels into PX/12+1 output rows (one input row each),
+  // plus the row above the first one and one row of slack for the partial first/last rows
+  static constexpr int PATCH = (PX / 12 + 3) * 12 + 16;
   static constexpr int OFF_W = (PATCH + 1) * M_PITCH * 2;       // bytes; row PATCH is all zero
   static constexpr int MAIN_END = OFF_W + 128 * M_PITCH * 2;
   static constexpr int T1_END = 32768 + NW * 32 * 144;          // ConvT#1 stage: operand half + per-wave store tiles
