@@ -1,0 +1,144 @@
+"""Counterpart of the reference's `ml_super_resolution` (the one call the solvers make
+between the coarse and the fine solve), on libsrcfd.
+
+    PyCFD_ML_accelerated.py:764-879   ml_super_resolution(coarse_fields, lr_dim, hr_dim,
+                                          stats_file, encoder_file, decoder_file)
+    bfs_ml_accelerated.py:979-1137    same + use_aspect_ratio_correction, lx, ly,
+                                          use_adaptive_normalization=True, blend_factor=0.3
+
+Order of operations is the reference's: float32 cast, [BFS: spline resample to a
+square], stats lookup, [BFS: adaptive blend], standardise, predict, de-standardise
+with the *training* HR stats, NaN/Inf zero-fill, [BFS: resample back].  Standardise,
+the network, de-standardise and the guard run as one device call for the three
+components; the 10x10 statistics and the splines stay on the host (scipy, as in
+the reference).
+"""
+from __future__ import annotations
+
+import os
+import warnings
+from typing import Dict, Optional
+
+import numpy as np
+
+from . import keras_compat as kc
+from .stats import load_stats
+
+COMPONENTS = ("u", "v", "p")
+
+
+def standardize_with_stats(arr, mean, std):
+    """PyCFD_ML_accelerated.py:665-668."""
+    std = 1e-8 if std == 0 else std
+    return (arr - mean) / std
+
+
+def inverse_standardize(arr, mean, std):
+    """PyCFD_ML_accelerated.py:671-673."""
+    return arr * std + mean
+
+
+def reshape_rectangular_to_square(fields, nx_rect, ny_rect, lx, ly):
+    """bfs_ml_accelerated.py:59-101 (bicubic RectBivariateSpline onto linspace(0,max(lx,ly))^2)."""
+    from scipy import interpolate
+    x_rect, y_rect = np.linspace(0, lx, nx_rect), np.linspace(0, ly, ny_rect)
+    L = max(lx, ly)
+    x_sq, y_sq = np.linspace(0, L, nx_rect), np.linspace(0, L, nx_rect)
+    out = {}
+    for c in COMPONENTS:
+        out[c] = interpolate.RectBivariateSpline(y_rect, x_rect, fields[c], kx=3, ky=3)(y_sq, x_sq)
+    return out
+
+
+def reshape_square_to_rectangular(fields, nx_rect, ny_rect, lx, ly):
+    """bfs_ml_accelerated.py:104-145."""
+    from scipy import interpolate
+    n = fields["u"].shape[0]
+    L = max(lx, ly)
+    x_sq, y_sq = np.linspace(0, L, n), np.linspace(0, L, n)
+    x_rect, y_rect = np.linspace(0, lx, nx_rect), np.linspace(0, ly, ny_rect)
+    out = {}
+    for c in COMPONENTS:
+        out[c] = interpolate.RectBivariateSpline(y_sq, x_sq, fields[c], kx=3, ky=3)(y_rect, x_rect)
+    return out
+
+
+def ml_super_resolution(coarse_fields: Dict[str, np.ndarray], lr_dim: int, hr_dim: int,
+                        stats_file: str, encoder_file: str, decoder_file: str,
+                        use_aspect_ratio_correction: bool = False, lx: float = 1.0, ly: float = 1.0,
+                        use_adaptive_normalization: bool = False, blend_factor: float = 0.3,
+                        precision: Optional[str] = None, verbose: bool = False) -> Dict[str, np.ndarray]:
+    """Lid-driven-cavity defaults (PyCFD_ML_accelerated.py:764); `ml_super_resolution_bfs`
+    has the backward-facing-step defaults.  Returns {'u','v','p'} -> (hr_dim, hr_dim) float32
+    (float64 after the BFS back-resampling, as scipy returns it)."""
+    say = print if verbose else (lambda *a, **k: None)
+    fields = coarse_fields
+    if use_aspect_ratio_correction and lx != ly:
+        fields = reshape_rectangular_to_square(coarse_fields, lr_dim, lr_dim, lx, ly)
+
+    stats_lr, stats_hr = load_stats(stats_file, lr_dim, hr_dim)  # FileNotFoundError / KeyError like :819-825
+    for f in (encoder_file, decoder_file):  # the callers pre-check this (:1080-1087); load_model would raise too
+        if not os.path.exists(f):
+            raise FileNotFoundError(f"model file '{f}' not found")
+    model = kc._device_handle((os.fspath(encoder_file), os.fspath(decoder_file)), precision or kc._DEFAULT_PRECISION)
+
+    x = np.empty((3, lr_dim, lr_dim, 1), np.float32)
+    ain = np.empty((3, 2), np.float32)
+    aout = np.empty((3, 2), np.float32)
+    for i, c in enumerate(COMPONENTS):
+        x_lr_raw = np.asarray(fields[c]).astype(np.float32)
+        mean_lr, std_lr = stats_lr[c]
+        if use_adaptive_normalization:  # bfs_ml_accelerated.py:1091-1097, same expressions
+            input_mean = np.mean(x_lr_raw)
+            input_std = np.std(x_lr_raw)
+            mean_lr = (1 - blend_factor) * mean_lr + blend_factor * input_mean
+            std_lr = (1 - blend_factor) * std_lr + blend_factor * max(input_std, 1e-8)
+            say(f"  {c.upper()}: adaptive norm (blend={blend_factor:.2f}) mean={float(mean_lr):.6f} std={float(std_lr):.6f}")
+        x[i, :, :, 0] = x_lr_raw
+        ain[i] = (mean_lr, std_lr)
+        aout[i] = stats_hr[c]
+
+    y, bad = model.predict(x, in_affine=ain, out_affine=aout, nan_guard=True, return_nonfinite=True)
+    if bad:
+        warnings.warn(f"super-resolved fields contained {bad} NaN/Inf values; replaced with zeros "
+                      "(PyCFD_ML_accelerated.py:869-876)", RuntimeWarning)
+    hr = {c: y[i, :, :, 0] for i, c in enumerate(COMPONENTS)}
+    for c in COMPONENTS:
+        say(f"  {c.upper()}: {fields[c].shape} -> {hr[c].shape}, range [{hr[c].min():.6f}, {hr[c].max():.6f}]")
+    if use_aspect_ratio_correction and lx != ly:
+        hr = reshape_square_to_rectangular(hr, hr_dim, hr_dim, lx, ly)
+    return hr
+
+
+def ml_super_resolution_bfs(coarse_fields, lr_dim, hr_dim, stats_file, encoder_file, decoder_file,
+                            use_aspect_ratio_correction: bool = False, lx: float = 1.0, ly: float = 1.0,
+                            use_adaptive_normalization: bool = True, blend_factor: float = 0.3, **kw):
+    """bfs_ml_accelerated.py:979-985 defaults."""
+    return ml_super_resolution(coarse_fields, lr_dim, hr_dim, stats_file, encoder_file, decoder_file,
+                               use_aspect_ratio_correction, lx, ly, use_adaptive_normalization, blend_factor, **kw)
+
+
+def inject_into_solver_state(hr_fields: Dict[str, np.ndarray], Var: np.ndarray) -> None:
+    """The consumer side of the boundary (PyCFD_ML_accelerated.py:936-938): write the SR
+    fields, transposed, into the interior of the solver's float64 `Var[k, 1:-1, 1:-1]`."""
+    for k, c in enumerate(COMPONENTS):
+        Var[k, 1:-1, 1:-1] = hr_fields[c].T
+
+
+def tiled_super_resolution(field: np.ndarray, model, lr_dim: int = 10, in_affine=None, out_affine=None) -> np.ndarray:
+    """BASELINE config 5: a (T*lr, T*lr, C) coarse field is cut into T x T non-overlapping
+    lr x lr tiles, each component of each tile super-resolved independently with the same
+    weights, and the 400x400 results stitched to (T*400, T*400, C).  No overlap or blending:
+    the reference defines none."""
+    H, W, C = field.shape
+    ty, tx = H // lr_dim, W // lr_dim
+    if ty * lr_dim != H or tx * lr_dim != W:
+        raise ValueError("field size must be a multiple of the tile size")
+    tiles = field.reshape(ty, lr_dim, tx, lr_dim, C).transpose(0, 2, 4, 1, 3).reshape(ty * tx * C, lr_dim, lr_dim, 1)
+    tiles = np.ascontiguousarray(tiles, dtype=np.float32)
+    n = tiles.shape[0]
+    ai = np.tile(np.asarray(in_affine, np.float32), (ty * tx, 1)) if in_affine is not None else None
+    ao = np.tile(np.asarray(out_affine, np.float32), (ty * tx, 1)) if out_affine is not None else None
+    y = model.predict(tiles, in_affine=ai, out_affine=ao)
+    hr = y.shape[1]
+    return y.reshape(ty, tx, C, hr, hr).transpose(0, 3, 1, 4, 2).reshape(ty * hr, tx * hr, C)
