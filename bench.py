@@ -119,6 +119,7 @@ def main():
 
     srcfd = importlib.import_module("sr-for-cfd_amd")
     synth = importlib.import_module("sr-for-cfd_amd.synth")
+    shard = importlib.import_module("sr-for-cfd_amd.shard")
     enc_w = srcfd.SRModel.load_h5(ENCODER_H5, None, device=-1).weights()   # real trained encoder (reference checkout)
     dec_w = synth.synthetic_decoder_weights(1)                              # decoder .h5 absent upstream -> random init
     model = srcfd.SRModel.from_weights(enc_w, dec_w, device=local_rank)
@@ -153,10 +154,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = shard.max_over_ranks(dt, device=dev)
     ms_per_step = dt / args.steps * 1e3
 
     # dominant-kernel timing with HIP events on the launch stream (rank 0)
@@ -183,7 +181,7 @@ def main():
             roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
                         "frac": round(ach / peak, 4), "traffic": None, "avg_launch_ms": kernels[dom],
                         "algorithmic_flops_per_launch": fl,
-                        "note": "swish needs 2 quarter-rate transcendentals per activation: VALU ceiling ~0.31 of MFMA peak (DESIGN.md)"}
+                        "note": "swish = 2 quarter-rate transcendentals per activation: the VALU ceiling of this network is ~0.45 of the MFMA peak (DESIGN.md 4.2)"}
         else:
             fl = 2.0 * MACS_PER_SAMPLE * n
             tot = sum(kernels.values())
@@ -199,7 +197,7 @@ def main():
         cpu = cpu_baseline(x_h, ain_h, aout_h, enc_w, dec_w, y32.cpu().numpy())
 
     if rank == 0:
-        value = args.fields * world / (ms_per_step * 1e-3)
+        value = shard.aggregate_throughput(args.fields, world, ms_per_step * 1e-3)
         out = {
             "metric": "SR fields/sec (10x10->400x400, 3-ch) @batch256", "value": round(value, 2), "unit": "fields/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),

@@ -191,6 +191,43 @@ __global__ void __launch_bounds__(256) gemm_mfma_f32(GemmDesc d, const float* __
 }
 
 // ---------------------------------------------------------------------------
+// single-output-channel conv (decoder's 3x3 8->1 `output_image_400`): the
+// GEMM tile would be 97 % padding at N=1, so one thread owns one output pixel and walks the
+// taps with 16-byte loads; same (ty,tx,ci) f32 FMA order as the oracle.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) conv_n1_f32(GemmDesc d, const float* __restrict__ X, const float* __restrict__ B,
+                                                    const float* __restrict__ bias, float* __restrict__ Y) {
+  __shared__ float w[512];
+  for (int i = threadIdx.x; i < d.K; i += 256) w[i] = B[(int64_t)i * d.Npad];
+  __syncthreads();
+  int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= d.M) return;
+  int img, my, mx;
+  row_decode(d, (int)m, img, my, mx);
+  float acc = bias[0];
+  for (int ty = 0; ty < d.TY; ++ty) {
+    int iy = my * d.ay + ty * d.by + d.cy;
+    if (iy < 0 || iy >= d.IH) continue;
+    for (int tx = 0; tx < d.TX; ++tx) {
+      int ix = mx * d.ax + tx * d.bx + d.cx;
+      if (ix < 0 || ix >= d.IW) continue;
+      const float* xp = X + (((int64_t)img * d.IH + iy) * d.IW + ix) * d.CI;
+      const float* wp = w + (ty * d.TX + tx) * d.CI;
+      if ((d.CI & 3) == 0) {
+        for (int ci = 0; ci < d.CI; ci += 4) {
+          float4 v = *reinterpret_cast<const float4*>(xp + ci);
+          acc = fmaf(v.x, wp[ci], acc); acc = fmaf(v.y, wp[ci + 1], acc);
+          acc = fmaf(v.z, wp[ci + 2], acc); acc = fmaf(v.w, wp[ci + 3], acc);
+        }
+      } else {
+        for (int ci = 0; ci < d.CI; ++ci) acc = fmaf(xp[ci], wp[ci], acc);
+      }
+    }
+  }
+  Y[out_offset(d, img, my, mx, 0)] = act_apply_precise(acc, d.act);
+}
+
+// ---------------------------------------------------------------------------
 // element-wise pre / post
 // ---------------------------------------------------------------------------
 // x := (x - mean) / std in float32, exactly numpy's float32 arithmetic
@@ -251,6 +288,10 @@ hipError_t launch_gemm_naive(const GemmDesc& d, const float* X, const float* B, 
 
 hipError_t launch_gemm_mfma(const GemmDesc& d, const float* X, const float* B, const float* bias, float* Y, hipStream_t s) {
   if (d.M == 0 || d.N == 0) return hipSuccess;
+  if (d.N == 1 && d.K <= 512 && d.nphx == 1) {
+    hipLaunchKernelGGL(conv_n1_f32, dim3((unsigned)((d.M + 255) / 256)), dim3(256), 0, s, d, X, B, bias, Y);
+    return hipGetLastError();
+  }
   bool vec = (d.CI % 16 == 0) && d.K > 0;
   int nb = (d.Npad % 128 == 0) ? 4 : ((d.Npad % 64 == 0) ? 2 : 1);
   dim3 grid((d.M + BM - 1) / BM, d.Npad / (32 * nb));

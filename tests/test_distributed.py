@@ -1,0 +1,73 @@
+"""world_size-2 gloo tests of the multi-process path bench.py uses: sample
+sharding without a data-path collective, barrier + MAX-over-ranks timing."""
+import importlib
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_total, out):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    shard = importlib.import_module("sr-for-cfd_amd.shard")
+    bench = importlib.import_module("bench")
+    lo, hi = shard.shard_range(n_total, rank, world)
+    # every rank builds its own synthetic batch (weak scaling), seeded by rank like bench.py
+    lr = {c: (0.1 * (i + 1), 0.2 + 0.1 * i) for i, c in enumerate("uvp")}
+    x, ain, aout = bench.build_inputs(4, seed=rank, stats_lr=lr, stats_hr=lr)
+    dist.barrier()
+    t = shard.max_over_ranks(0.5 + rank)  # rank 1 is "slower"
+    gathered = [None] * world
+    dist.all_gather_object(gathered, (lo, hi, float(x.sum())))
+    if rank == 0:
+        out.put((t, gathered, x.shape, ain.tolist()))
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharding_and_timing():
+    world, n_total = 2, 769
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    t, gathered, shape, ain = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert t == 1.5  # MAX over ranks
+    (lo0, hi0, s0), (lo1, hi1, s1) = gathered
+    assert (lo0, hi0, lo1, hi1) == (0, 385, 385, 769)  # contiguous, disjoint, covering, sizes differ by <= 1
+    assert s0 != s1  # ranks generate different synthetic batches
+    assert shape == (12, 10, 10, 1)
+    assert ain[0] == pytest.approx([0.1, 0.2]) and ain[4] == pytest.approx([0.2, 0.3])  # sample 3f+c carries component c's stats
+
+
+def test_shard_range_properties():
+    shard = importlib.import_module("sr-for-cfd_amd.shard")
+    for n in (0, 1, 7, 48, 768):
+        for w in (1, 2, 3, 8):
+            spans = [shard.shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard.shard_range(10, 2, 2)
+    assert shard.aggregate_throughput(256, 8, 0.001) == 256 * 8 / 0.001
