@@ -69,6 +69,7 @@ typedef struct {
 typedef struct srcfd_model srcfd_model;
 typedef struct srcfd_h5 srcfd_h5;
 typedef struct srcfd_h5w srcfd_h5w;
+typedef struct srcfd_trainer srcfd_trainer;
 
 const char* srcfd_last_error(void);
 const char* srcfd_version(void);
@@ -181,6 +182,27 @@ int srcfd_h5w_save(srcfd_h5w* w, const char* path);
 /* Saves the handle's weights as legacy Keras-H5 sub-model files
  * (sr-ae-conv.ipynb:c584-585); split_at = index of the first decoder layer. */
 int srcfd_model_save_h5(const srcfd_model* m, const char* encoder_h5, const char* decoder_h5);
+
+/* ---- training -----------------------------------------------------------
+ * One optimisation step of SuperResolutionAE, split so that a data-parallel driver can put its
+ * gradient all-reduce between the two halves (one flat f32 buffer per step).
+ * Replaces `SuperResolutionAE.train_step` + `Adam()` (sr-ae-conv.ipynb:c306-320, c556).
+ * Parameters, gradients and Adam moments are caller-owned flat f32 DEVICE arrays in Keras'
+ * trainable_weights order (per layer: kernel then bias, Keras layouts); srcfd_trainer_get_params
+ * returns the model's current values in that order (host). */
+int srcfd_trainer_create(const srcfd_model* m, int max_batch, srcfd_trainer** out);
+void srcfd_trainer_destroy(srcfd_trainer* t);
+int64_t srcfd_trainer_num_params(const srcfd_trainer* t);
+int srcfd_trainer_get_params(const srcfd_trainer* t, float* params_host);
+/* Forward + backward on n <= max_batch samples: x_dev (n,h,w,c) inputs, y_dev targets of the model's
+ * output shape.  ADDS d/dparams of loss_scale * sum((pred - y)^2) into grads_dev (zero it first; pass
+ * loss_scale = 1 / (global batch * output elements) for Keras' reduce_mean(mse)) and adds the local sum of
+ * squared errors to *sse_dev (device double, may be NULL).  Enqueues on hip_stream, no synchronisation. */
+int srcfd_trainer_forward_backward(srcfd_trainer* t, const float* params_dev, const float* x_dev, const float* y_dev, int n,
+                                   float loss_scale, float* grads_dev, double* sse_dev, void* hip_stream);
+/* Keras Adam update, step counted from 1: alpha_t = lr*sqrt(1-beta2^t)/(1-beta1^t); p -= alpha_t*m/(sqrt(v)+eps). */
+int srcfd_adam_step(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, int64_t n, int step, float lr,
+                    float beta1, float beta2, float eps, void* hip_stream);
 
 #ifdef __cplusplus
 }

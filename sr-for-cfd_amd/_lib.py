@@ -73,6 +73,12 @@ _protos = {
     "srcfd_model_get_profile": (C.c_int, [_p, C.c_char_p, _sz, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]),
     "srcfd_model_debug_activation": (C.c_int, [_p, C.c_int, _p, _sz]),
     "srcfd_model_save_h5": (C.c_int, [_p, C.c_char_p, C.c_char_p]),
+    "srcfd_trainer_create": (C.c_int, [_p, C.c_int, C.POINTER(_p)]),
+    "srcfd_trainer_destroy": (None, [_p]),
+    "srcfd_trainer_num_params": (C.c_int64, [_p]),
+    "srcfd_trainer_get_params": (C.c_int, [_p, _p]),
+    "srcfd_trainer_forward_backward": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_float, _p, _p, _p]),
+    "srcfd_adam_step": (C.c_int, [_p, _p, _p, _p, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, _p]),
     "srcfd_stats_load": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "srcfd_stats_save": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "srcfd_h5_open": (C.c_int, [C.c_char_p, C.POINTER(_p)]),

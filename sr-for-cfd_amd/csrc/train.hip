@@ -1,0 +1,505 @@
+// Training step of SuperResolutionAE on gfx950 (f32): forward with saved pre-activations,
+// MSE loss, backward (data + weight gradients of every layer), Adam.
+//
+// Reference: sr-ae-conv.ipynb:c306-320 (`train_step`: loss = reduce_mean(mse(x_hr, pred)),
+// tape.gradient over all trainable weights, optimizer.apply_gradients) and c556 (`Adam()` with
+// Keras defaults).  Data parallelism lives above this file: every rank calls
+// srcfd_trainer_forward_backward on its micro-batch with loss_scale = 1 / (global batch x 160000),
+// all-reduces the flat gradient buffer once (RCCL through torch.distributed), then srcfd_adam_step.
+//
+// Every layer is the same implicit GEMM the inference engine uses (kernels_fp32.hip):
+//   forward  Z = A(X) B + bias           (gemm_mfma_f32, linear epilogue; swish applied by swish_fwd)
+//   dgrad    dX = A'(dZ) B'              (the SAME kernel with a transposed gather descriptor:
+//                                         Conv2D -> flipped-tap conv, Conv2DTranspose -> strided conv, Dense -> W^T)
+//   wgrad    dB = A(X)^T dZ  (+ bias row) (wgrad_f32 below: the GEMM reduction runs over pixels)
+// Weights live in ONE flat f32 buffer in Keras' trainable_weights order; index maps built once on the
+// host scatter them into the packed per-op operand buffers and gather the packed gradients back.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "engine.h"
+
+namespace srcfd {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define HIPCHECK(expr)                                                               \
+  do {                                                                               \
+    hipError_t _e = (expr);                                                          \
+    if (_e != hipSuccess) {                                                          \
+      set_error(std::string(#expr) + " failed: " + hipGetErrorString(_e));           \
+      return SRCFD_EHIP;                                                             \
+    }                                                                                \
+  } while (0)
+
+// ---------------------------------------------------------------------------
+// element-wise kernels
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) swish_fwd_f32(const float* __restrict__ z, float* __restrict__ y, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { float v = z[i]; y[i] = v / (1.0f + expf(-v)); }
+}
+
+// dz = dy * swish'(z), swish'(z) = s + z s (1 - s), s = sigmoid(z); in place on dy
+__global__ void __launch_bounds__(256) swish_bwd_f32(const float* __restrict__ z, float* __restrict__ dy, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    float v = z[i], s = 1.0f / (1.0f + expf(-v));
+    dy[i] *= s + v * s * (1.0f - s);
+  }
+}
+
+// dpred = 2 * scale * (pred - y); per-block partial sums of squared error (fixed order -> reproducible)
+__global__ void __launch_bounds__(256) mse_grad_f32(const float* __restrict__ pred, const float* __restrict__ y, float* __restrict__ dpred,
+                                                     int64_t n, float scale, double* __restrict__ partial) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    float e = pred[i] - y[i];
+    dpred[i] = 2.0f * scale * e;
+    acc += (double)e * (double)e;
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ void sum_partials_f64(const double* __restrict__ partial, int n, double* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i) s += partial[i];
+    *out += s;
+  }
+}
+
+// dst[i] = map[i] > 0 ? src[map[i]-1] : 0   (flat params -> packed operand buffers)
+__global__ void __launch_bounds__(256) gather_pack_f32(const float* __restrict__ src, const int* __restrict__ map, float* __restrict__ dst, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { int k = map[i]; dst[i] = k > 0 ? src[k - 1] : 0.f; }
+}
+
+// Keras Adam (sr-ae-conv.ipynb:c556 defaults): m,v moments, alpha_t = lr sqrt(1-b2^t)/(1-b1^t), p -= alpha_t m/(sqrt(v)+eps)
+__global__ void __launch_bounds__(256) adam_f32(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                 int64_t n, float alpha_t, float b1, float b2, float eps) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    float gi = g[i];
+    float mi = b1 * m[i] + (1.0f - b1) * gi;
+    float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    p[i] -= alpha_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// weight gradient: dB[k][n] = sum_m A[m][k] * dZ[m][n], plus the bias row k == K (A = 1).
+// One wave = one 32(k) x 32(n) tile over one slice of the rows; v_mfma_f32_32x32x2_f32 with the
+// row index m as the MFMA's reduction dimension.  Partial tiles go to part[slice][k][n] and are
+// summed in slice order by wgrad_finish (reproducible), which also scatters into the flat gradient.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) wgrad_f32(GemmDesc d, const float* __restrict__ X, const float* __restrict__ dZ, float* __restrict__ part,
+                                                  int rows_per_slice, int nslices, int ktiles) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slice = blockIdx.y * 4 + wave;
+  if (slice >= nslices) return;
+  const int kt = blockIdx.x % ktiles, nt = blockIdx.x / ktiles;
+  const int l31 = lane & 31, hh = lane >> 5;
+  // this lane's A column (k) and dZ column (n)
+  const int k = kt * 32 + l31;
+  const bool is_bias = k == d.K, k_ok = k < d.K;
+  int ty = 0, tx = 0, ci = 0;
+  if (k_ok) { int tap = k / d.CI; ci = k - tap * d.CI; ty = tap / d.TX; tx = tap - ty * d.TX; }
+  const int n = nt * 32 + l31;
+  const bool n_ok = n < d.N;
+  int py = 0, px = 0, co = 0;
+  if (n_ok) { int ph = n / d.CO; co = n - ph * d.CO; py = ph / d.nphx; px = ph - py * d.nphx; }
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int m_beg = slice * rows_per_slice, m_end = min(d.M, m_beg + rows_per_slice);
+  const int per = d.MH * d.MW;
+  for (int m0 = m_beg; m0 < m_end; m0 += 2) {
+    const int m = m0 + hh;
+    float a = 0.f, b = 0.f;
+    if (m < m_end) {
+      int img = m / per, r = m - img * per, my = r / d.MW, mx = r - my * d.MW;
+      if (is_bias) a = 1.f;
+      else if (k_ok) {
+        int iy = my * d.ay + ty * d.by + d.cy, ix = mx * d.ax + tx * d.bx + d.cx;
+        if (iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW) a = X[(((int64_t)img * d.IH + iy) * d.IW + ix) * d.CI + ci];
+      }
+      if (n_ok) {
+        int oy = my * d.os + d.oy0 + py, ox = mx * d.os + d.ox0 + px;
+        b = dZ[(((int64_t)img * d.OH + oy) * d.OW + ox) * d.OC + co];
+      }
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+  }
+  // D[row = k in tile][col = n in tile]
+  float* out = part + ((int64_t)slice * (d.K + 1)) * d.Npad;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int kk = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+    if (kk <= d.K && n_ok) out[(int64_t)kk * d.Npad + n] = acc[r];
+  }
+}
+
+// grads[map[i]-1] += sum_slices part[slice][i]   for the (K+1) x Npad elements of one op.  In the bias
+// row of a merged-phase op (kernel == stride transposed conv) the N/CO phase columns of one channel
+// all map to the same parameter: the thread of phase 0 sums them in phase order (no atomics).
+__global__ void __launch_bounds__(256) wgrad_finish_f32(const float* __restrict__ part, int nslices, int64_t elems, const int* __restrict__ map,
+                                                         float* __restrict__ grads, int K, int N, int Npad, int CO) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= elems) return;
+  int k = map[i];
+  if (k <= 0) return;
+  const int row = (int)(i / Npad), col = (int)(i - (int64_t)row * Npad);
+  float s = 0.f;
+  if (row == K) {
+    if (col >= CO) return;
+    for (int c = col; c < N; c += CO)
+      for (int z = 0; z < nslices; ++z) s += part[(int64_t)z * elems + (int64_t)row * Npad + c];
+  } else {
+    for (int z = 0; z < nslices; ++z) s += part[(int64_t)z * elems + i];
+  }
+  grads[k - 1] += s;
+}
+
+// ---------------------------------------------------------------------------
+// trainer
+// ---------------------------------------------------------------------------
+struct TrainOp {
+  GemmDesc fwd;           // forward descriptor (act forced linear)
+  size_t w_off, b_off;    // into the packed forward buffer (same layout as Model::pack)
+  int layer;              // compute-layer ordinal
+  // dgrad (absent for the first layer)
+  // wgrad
+  std::vector<int> gmap;  // (K+1) x Npad -> flat param index + 1 (0: padding)
+  int* d_gmap = nullptr;
+  int nslices = 1, rows_per_slice = 0;
+};
+
+struct DgradOp {
+  GemmDesc d;
+  size_t w_off;  // into the packed dgrad buffer
+  int layer;     // compute layer whose INPUT gradient this produces
+};
+
+struct LayerInfo {
+  int desc_index;              // into ModelDesc::layers
+  size_t in_elems, out_elems;  // per sample
+  bool swish;
+  size_t kernel_off, bias_off; // flat param offsets
+};
+
+struct Trainer {
+  int device = 0;
+  int max_batch = 0;
+  ModelDesc desc;                 // own copy (shapes)
+  std::vector<LayerInfo> layers;  // compute layers
+  std::vector<TrainOp> ops;
+  std::vector<DgradOp> dops;
+  int64_t n_params = 0;
+  std::vector<float> init_params;
+  // device
+  float* d_pack = nullptr; int* d_pack_map = nullptr; size_t pack_elems = 0;
+  float* d_dpack = nullptr; int* d_dpack_map = nullptr; size_t dpack_elems = 0;
+  float* d_zero_bias = nullptr; size_t zero_bias_elems = 0;
+  std::vector<float*> Z, Y;       // per compute layer (Y aliases Z for linear layers)
+  float* dbuf[2] = {nullptr, nullptr};
+  float* d_part = nullptr; size_t part_elems = 0;
+  double* d_loss_partial = nullptr;
+  ~Trainer();
+};
+
+Trainer::~Trainer() {
+  (void)hipSetDevice(device);
+  for (void* p : {(void*)d_pack, (void*)d_pack_map, (void*)d_dpack, (void*)d_dpack_map, (void*)d_zero_bias, (void*)dbuf[0], (void*)dbuf[1],
+                  (void*)d_part, (void*)d_loss_partial})
+    if (p) (void)hipFree(p);
+  for (size_t i = 0; i < Z.size(); ++i) {
+    if (Y[i] && Y[i] != Z[i]) (void)hipFree(Y[i]);
+    if (Z[i]) (void)hipFree(Z[i]);
+  }
+  for (auto& o : ops) if (o.d_gmap) (void)hipFree(o.d_gmap);
+}
+
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// Replaces every weight by (its flat index + 1) as a float: running the ordinary packers on this
+// "index model" yields, for each packed slot, which parameter lands there (0 = padding).
+static ModelDesc index_model(const ModelDesc& src, std::vector<LayerInfo>& layers, int64_t& n_params, std::vector<float>& init) {
+  ModelDesc im = src;
+  int64_t off = 0;
+  layers.clear();
+  init.clear();
+  for (size_t li = 0; li < im.layers.size(); ++li) {
+    Layer& L = im.layers[li];
+    if (L.kernel.empty()) continue;
+    LayerInfo info;
+    info.desc_index = (int)li;
+    info.in_elems = (size_t)L.in_shape[0] * L.in_shape[1] * L.in_shape[2];
+    info.out_elems = (size_t)L.out_shape[0] * L.out_shape[1] * L.out_shape[2];
+    info.swish = L.act == SRCFD_ACT_SWISH;
+    info.kernel_off = (size_t)off;
+    init.insert(init.end(), L.kernel.begin(), L.kernel.end());
+    for (size_t i = 0; i < L.kernel.size(); ++i) L.kernel[i] = (float)(off + (int64_t)i + 1);
+    off += (int64_t)L.kernel.size();
+    info.bias_off = (size_t)off;
+    init.insert(init.end(), L.bias.begin(), L.bias.end());
+    for (size_t i = 0; i < L.bias.size(); ++i) L.bias[i] = (float)(off + (int64_t)i + 1);
+    off += (int64_t)L.bias.size();
+    layers.push_back(info);
+  }
+  n_params = off;
+  return im;
+}
+
+// dgrad descriptors + packed operands (values taken from `md`, which may be the index model)
+static void build_dgrad(const ModelDesc& md, const std::vector<LayerInfo>& layers, std::vector<DgradOp>& dops, std::vector<float>& pack) {
+  dops.clear();
+  pack.clear();
+  for (size_t ci = 1; ci < layers.size(); ++ci) {  // the first layer's input needs no gradient
+    const Layer& L = md.layers[layers[ci].desc_index];
+    const int IH = L.in_shape[0], IW = L.in_shape[1], OH = L.out_shape[0], OW = L.out_shape[1];
+    GemmDesc d{};
+    d.act = SRCFD_ACT_LINEAR;
+    d.nphx = 1; d.os = 1;
+    d.N = L.cin; d.Npad = round_up(d.N, 32); d.CO = L.cin; d.OC = L.cin;
+    std::vector<float> B;
+    if (L.kind == SRCFD_LAYER_DENSE) {
+      d.MH = d.MW = 1; d.TY = d.TX = 1; d.CI = L.cout; d.IH = d.IW = 1; d.OH = d.OW = 1;
+      d.K = L.cout;
+      B.resize((size_t)d.K * d.N);
+      for (int co = 0; co < L.cout; ++co)
+        for (int c = 0; c < L.cin; ++c) B[(size_t)co * d.N + c] = L.kernel[(size_t)c * L.cout + co];
+    } else if (L.kind == SRCFD_LAYER_CONV2D) {
+      if (L.stride != 1) throw std::runtime_error("training: strided Conv2D is only supported as the first layer");
+      int pt = 0, pl = 0;
+      if (L.same) { pt = std::max((OH - 1) + L.kh - IH, 0) / 2; pl = std::max((OW - 1) + L.kw - IW, 0) / 2; }
+      d.MH = IH; d.MW = IW; d.TY = L.kh; d.TX = L.kw; d.CI = L.cout; d.IH = OH; d.IW = OW; d.OH = IH; d.OW = IW;
+      d.ay = d.ax = 1; d.by = d.bx = -1; d.cy = pt; d.cx = pl;
+      d.K = L.kh * L.kw * L.cout;
+      B.resize((size_t)d.K * d.N);
+      for (int ky = 0; ky < L.kh; ++ky)
+        for (int kx = 0; kx < L.kw; ++kx)
+          for (int co = 0; co < L.cout; ++co)
+            for (int c = 0; c < L.cin; ++c)
+              B[((size_t)(ky * L.kw + kx) * L.cout + co) * d.N + c] = L.kernel[(((size_t)ky * L.kw + kx) * L.cin + c) * L.cout + co];
+    } else {  // Conv2DTranspose VALID, kernel (kh,kw,Cout,Cin): dX[i,j,ci] = sum dZ[s i + a, s j + b, co] W[a,b,co,ci]
+      d.MH = IH; d.MW = IW; d.TY = L.kh; d.TX = L.kw; d.CI = L.cout; d.IH = OH; d.IW = OW; d.OH = IH; d.OW = IW;
+      d.ay = d.ax = L.stride; d.by = d.bx = 1; d.cy = d.cx = 0;
+      d.K = L.kh * L.kw * L.cout;
+      B = L.kernel;  // already [(a,b,co)][ci]
+    }
+    DgradOp op;
+    op.d = d;
+    op.layer = (int)ci;
+    while (pack.size() % 64) pack.push_back(0.f);
+    op.w_off = pack.size();
+    pack.resize(pack.size() + (size_t)d.K * d.Npad, 0.f);
+    for (int k = 0; k < d.K; ++k) std::memcpy(&pack[op.w_off + (size_t)k * d.Npad], &B[(size_t)k * d.N], sizeof(float) * d.N);
+    dops.push_back(op);
+  }
+}
+
+static int upload_map(const std::vector<float>& as_float, int** d_map) {
+  std::vector<int> m(as_float.size());
+  for (size_t i = 0; i < as_float.size(); ++i) m[i] = (int)as_float[i];
+  HIPCHECK(hipMalloc(d_map, std::max<size_t>(m.size(), 1) * sizeof(int)));
+  HIPCHECK(hipMemcpy(*d_map, m.data(), m.size() * sizeof(int), hipMemcpyHostToDevice));
+  return SRCFD_OK;
+}
+
+static int trainer_build(Trainer& t, const Model& model, int max_batch) {
+  t.device = model.device;
+  t.max_batch = max_batch;
+  t.desc = model.desc;
+  HIPCHECK(hipSetDevice(t.device));
+  ModelDesc im = index_model(t.desc, t.layers, t.n_params, t.init_params);
+  if (t.n_params >= (1 << 24)) { set_error("training: more than 2^24 parameters"); return SRCFD_EINVAL; }
+  if (t.layers.empty()) { set_error("training: model has no weights"); return SRCFD_EINVAL; }
+  // forward plan over the index model: same descriptors and packed layout as inference
+  std::vector<Op> iops;
+  std::vector<float> ipack;
+  build_plan(im, iops, ipack);
+  t.pack_elems = ipack.size();
+  int rc = upload_map(ipack, &t.d_pack_map);
+  if (rc) return rc;
+  HIPCHECK(hipMalloc(&t.d_pack, t.pack_elems * sizeof(float)));
+  size_t part_need = 1;
+  for (const Op& op : iops) {
+    TrainOp to;
+    to.fwd = op.d;
+    to.fwd.act = SRCFD_ACT_LINEAR;
+    to.w_off = op.w_off; to.b_off = op.b_off;
+    int ci = -1;
+    for (size_t k = 0; k < t.layers.size(); ++k) if (t.layers[k].desc_index == op.layer) ci = (int)k;
+    to.layer = ci;
+    // gradient map: rows 0..K-1 = operand rows, row K = bias
+    const GemmDesc& d = op.d;
+    to.gmap.assign((size_t)(d.K + 1) * d.Npad, 0);
+    for (int k = 0; k < d.K; ++k)
+      for (int n = 0; n < d.N; ++n) to.gmap[(size_t)k * d.Npad + n] = (int)ipack[op.w_off + (size_t)k * d.Npad + n];
+    for (int n = 0; n < d.N; ++n) to.gmap[(size_t)d.K * d.Npad + n] = (int)ipack[op.b_off + n];
+    HIPCHECK(hipMalloc(&to.d_gmap, to.gmap.size() * sizeof(int)));
+    HIPCHECK(hipMemcpy(to.d_gmap, to.gmap.data(), to.gmap.size() * sizeof(int), hipMemcpyHostToDevice));
+    const int64_t Mmax = (int64_t)max_batch * d.MH * d.MW;
+    to.nslices = (int)std::max<int64_t>(1, std::min<int64_t>(512, Mmax / 2048));
+    part_need = std::max(part_need, (size_t)to.nslices * to.gmap.size());
+    t.ops.push_back(std::move(to));
+  }
+  t.part_elems = part_need;
+  HIPCHECK(hipMalloc(&t.d_part, t.part_elems * sizeof(float)));
+  // dgrad plan
+  std::vector<float> dpack;
+  build_dgrad(im, t.layers, t.dops, dpack);
+  t.dpack_elems = dpack.size();
+  rc = upload_map(dpack, &t.d_dpack_map);
+  if (rc) return rc;
+  HIPCHECK(hipMalloc(&t.d_dpack, std::max<size_t>(t.dpack_elems, 1) * sizeof(float)));
+  int maxn = 32;
+  for (auto& o : t.dops) maxn = std::max(maxn, o.d.Npad);
+  t.zero_bias_elems = maxn;
+  HIPCHECK(hipMalloc(&t.d_zero_bias, maxn * sizeof(float)));
+  HIPCHECK(hipMemset(t.d_zero_bias, 0, maxn * sizeof(float)));
+  // activations
+  size_t maxe = t.layers[0].in_elems;
+  for (auto& L : t.layers) {
+    maxe = std::max(maxe, L.out_elems);
+    float *z = nullptr, *y = nullptr;
+    HIPCHECK(hipMalloc(&z, (size_t)max_batch * L.out_elems * sizeof(float)));
+    if (L.swish) HIPCHECK(hipMalloc(&y, (size_t)max_batch * L.out_elems * sizeof(float)));
+    else y = z;
+    t.Z.push_back(z);
+    t.Y.push_back(y);
+  }
+  for (auto*& b : t.dbuf) HIPCHECK(hipMalloc(&b, (size_t)max_batch * maxe * sizeof(float)));
+  HIPCHECK(hipMalloc(&t.d_loss_partial, 1024 * sizeof(double)));
+  return SRCFD_OK;
+}
+
+static int trainer_step(Trainer& t, const float* params, const float* x, const float* y, int n, float loss_scale, float* grads, double* sse_dev,
+                        hipStream_t s) {
+  if (n <= 0 || n > t.max_batch) { set_error("training: batch outside [1, max_batch]"); return SRCFD_EINVAL; }
+  HIPCHECK(hipSetDevice(t.device));
+  auto grid = [](int64_t n_) { return dim3((unsigned)((n_ + 255) / 256)); };
+  // 1. pack operands from the flat parameters
+  hipLaunchKernelGGL(gather_pack_f32, grid(t.pack_elems), dim3(256), 0, s, params, t.d_pack_map, t.d_pack, (int64_t)t.pack_elems);
+  if (t.dpack_elems) hipLaunchKernelGGL(gather_pack_f32, grid(t.dpack_elems), dim3(256), 0, s, params, t.d_dpack_map, t.d_dpack, (int64_t)t.dpack_elems);
+  // 2. forward, keeping Z (pre-activation) and Y (post) of every layer
+  for (const TrainOp& op : t.ops) {
+    GemmDesc d = op.fwd;
+    d.M = n * d.MH * d.MW;
+    const float* X = op.layer == 0 ? x : t.Y[op.layer - 1];
+    HIPCHECK(launch_gemm_mfma(d, X, t.d_pack + op.w_off, t.d_pack + op.b_off, t.Z[op.layer], s));
+    const bool last_of_layer = (&op == &t.ops.back()) || ((&op + 1)->layer != op.layer);
+    if (last_of_layer && t.layers[op.layer].swish) {
+      int64_t e = (int64_t)n * t.layers[op.layer].out_elems;
+      hipLaunchKernelGGL(swish_fwd_f32, grid(e), dim3(256), 0, s, t.Z[op.layer], t.Y[op.layer], e);
+    }
+  }
+  // 3. loss and its gradient (sr-ae-conv.ipynb:c314): sum of squared errors; dpred = 2 scale (pred - y)
+  const int L = (int)t.layers.size();
+  int64_t oe = (int64_t)n * t.layers[L - 1].out_elems;
+  int nb = (int)std::min<int64_t>(1024, (oe + 255) / 256);
+  hipLaunchKernelGGL(mse_grad_f32, dim3(nb), dim3(256), 0, s, t.Y[L - 1], y, t.dbuf[0], oe, loss_scale, t.d_loss_partial);
+  if (sse_dev) hipLaunchKernelGGL(sum_partials_f64, dim3(1), dim3(64), 0, s, t.d_loss_partial, nb, sse_dev);
+  // 4. backward
+  int cur = 0;
+  for (int li = L - 1; li >= 0; --li) {
+    float* dZ = t.dbuf[cur];
+    int64_t e = (int64_t)n * t.layers[li].out_elems;
+    if (t.layers[li].swish) hipLaunchKernelGGL(swish_bwd_f32, grid(e), dim3(256), 0, s, t.Z[li], dZ, e);
+    const float* X = li == 0 ? x : t.Y[li - 1];
+    for (const TrainOp& op : t.ops) {
+      if (op.layer != li) continue;
+      GemmDesc d = op.fwd;
+      d.M = n * d.MH * d.MW;
+      const int ktiles = (d.K + 1 + 31) / 32, ntiles = (d.N + 31) / 32;
+      int nslices = (int)std::max<int64_t>(1, std::min<int64_t>(op.nslices, ((int64_t)d.M + 2047) / 2048));
+      int rps = (d.M + nslices - 1) / nslices;
+      rps = (rps + 1) & ~1;
+      nslices = (d.M + rps - 1) / rps;
+      const int64_t elems = (int64_t)(d.K + 1) * d.Npad;
+      hipLaunchKernelGGL(wgrad_f32, dim3(ktiles * ntiles, (nslices + 3) / 4), dim3(256), 0, s, d, X, dZ, t.d_part, rps, nslices, ktiles);
+      hipLaunchKernelGGL(wgrad_finish_f32, grid(elems), dim3(256), 0, s, t.d_part, nslices, elems, op.d_gmap, grads, d.K, d.N, d.Npad, d.CO);
+    }
+    if (li > 0) {
+      const DgradOp& dg = t.dops[li - 1];
+      GemmDesc d = dg.d;
+      d.M = n * d.MH * d.MW;
+      HIPCHECK(launch_gemm_mfma(d, dZ, t.d_dpack + dg.w_off, t.d_zero_bias, t.dbuf[cur ^ 1], s));
+      cur ^= 1;
+    }
+  }
+  HIPCHECK(hipGetLastError());
+  return SRCFD_OK;
+}
+
+}  // namespace srcfd
+
+using srcfd::set_error;
+using srcfd::Trainer;
+
+extern "C" {
+
+int srcfd_trainer_create(const srcfd_model* m, int max_batch, srcfd_trainer** out) {
+  if (!m || !out || max_batch <= 0) { set_error("srcfd_trainer_create: bad arguments"); return SRCFD_EINVAL; }
+  *out = nullptr;
+  const srcfd::Model* mm = reinterpret_cast<const srcfd::Model*>(m);
+  if (mm->device < 0) { set_error("training needs a device handle"); return SRCFD_ENODEV; }
+  std::unique_ptr<Trainer> t(new Trainer());
+  try {
+    int rc = srcfd::trainer_build(*t, *mm, max_batch);
+    if (rc) return rc;
+  } catch (const std::exception& e) {
+    set_error(e.what());
+    return SRCFD_EINVAL;
+  }
+  *out = reinterpret_cast<srcfd_trainer*>(t.release());
+  return SRCFD_OK;
+}
+
+void srcfd_trainer_destroy(srcfd_trainer* t) { delete reinterpret_cast<Trainer*>(t); }
+
+int64_t srcfd_trainer_num_params(const srcfd_trainer* t) { return t ? reinterpret_cast<const Trainer*>(t)->n_params : 0; }
+
+int srcfd_trainer_get_params(const srcfd_trainer* t, float* params_host) {
+  if (!t || !params_host) { set_error("bad arguments"); return SRCFD_EINVAL; }
+  const Trainer* tt = reinterpret_cast<const Trainer*>(t);
+  std::memcpy(params_host, tt->init_params.data(), tt->init_params.size() * sizeof(float));
+  return SRCFD_OK;
+}
+
+int srcfd_trainer_forward_backward(srcfd_trainer* t, const float* params_dev, const float* x_dev, const float* y_dev, int n, float loss_scale,
+                                   float* grads_dev, double* sse_dev, void* hip_stream) {
+  if (!t || !params_dev || !x_dev || !y_dev || !grads_dev) { set_error("bad arguments"); return SRCFD_EINVAL; }
+  return srcfd::trainer_step(*reinterpret_cast<Trainer*>(t), params_dev, x_dev, y_dev, n, loss_scale, grads_dev, sse_dev,
+                             reinterpret_cast<hipStream_t>(hip_stream));
+}
+
+int srcfd_adam_step(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, int64_t n, int step, float lr, float beta1,
+                    float beta2, float eps, void* hip_stream) {
+  if (!params_dev || !grads_dev || !m_dev || !v_dev || n < 0 || step < 1) { set_error("bad arguments"); return SRCFD_EINVAL; }
+  if (n == 0) return SRCFD_OK;
+  const float alpha_t = (float)((double)lr * std::sqrt(1.0 - std::pow((double)beta2, step)) / (1.0 - std::pow((double)beta1, step)));
+  hipLaunchKernelGGL(srcfd::adam_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), params_dev,
+                     grads_dev, m_dev, v_dev, n, alpha_t, beta1, beta2, eps);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error(hipGetErrorString(e)); return SRCFD_EHIP; }
+  return SRCFD_OK;
+}
+
+}  // extern "C"

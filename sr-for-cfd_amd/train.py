@@ -1,0 +1,173 @@
+"""Training of SuperResolutionAE on libsrcfd (sr-ae-conv.ipynb:c289-320, c546-560).
+
+`Trainer.step(x_lr, x_hr)` = one `train_step`: loss = mean over all elements of (x_hr - pred)^2,
+gradients for every trainable weight, Keras-default Adam.  Data parallel over the GPUs of one
+node: one process per GPU, identical replicas, every rank runs forward/backward on its own
+micro-batch with the loss normalised by the GLOBAL batch, then ONE all-reduce(sum) over the flat
+2 709 491-float gradient buffer (RCCL through `torch.distributed`, backend "nccl"), then the same
+Adam update everywhere.  torch is used for device buffers and the collective only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Iterator, List, Optional, Tuple
+
+import numpy as np
+
+from . import _lib as L
+from .engine import SRModel
+
+
+def allreduce_sum_(flat_grads) -> None:
+    """The step's only collective: in-place SUM over ranks of the flat gradient tensor."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
+
+
+def world_size() -> int:
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank() -> int:
+    import torch.distributed as dist
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+def epoch_batches(n_samples: int, batch_size: int, epoch: int, seed: int, rank_: int = 0, world: int = 1) -> Iterator[np.ndarray]:
+    """`Dataset.shuffle(len).batch(batch_size)` reshuffled every epoch (sr-ae-conv.ipynb:c558): a
+    seeded permutation per epoch, cut into global batches of batch_size*world; each rank takes its
+    contiguous slice of every global batch (the last one may be ragged, like Keras')."""
+    perm = np.random.default_rng([seed, epoch]).permutation(n_samples)
+    gb = batch_size * world
+    for lo in range(0, n_samples, gb):
+        idx = perm[lo:lo + gb]
+        per = -(-len(idx) // world)
+        yield idx[rank_ * per:(rank_ + 1) * per]
+
+
+class Trainer:
+    def __init__(self, model: SRModel, max_batch: int = 8, lr: float = 1e-3, beta1: float = 0.9, beta2: float = 0.999,
+                 eps: float = 1e-7):
+        import torch
+        if model.device < 0:
+            raise L.NoDeviceError("training needs a device handle")
+        self.model = model
+        self.device = torch.device("cuda", model.device)
+        self._h = C.c_void_p()
+        L.check(L.lib.srcfd_trainer_create(model._h, int(max_batch), C.byref(self._h)))
+        self.n_params = int(L.lib.srcfd_trainer_num_params(self._h))
+        host = np.empty(self.n_params, np.float32)
+        L.check(L.lib.srcfd_trainer_get_params(self._h, host.ctypes.data_as(C.c_void_p)))
+        self.params = torch.from_numpy(host).to(self.device)
+        self.grads = torch.zeros_like(self.params)
+        self.m = torch.zeros_like(self.params)
+        self.v = torch.zeros_like(self.params)
+        self.sse = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self.lr, self.beta1, self.beta2, self.eps = lr, beta1, beta2, eps
+        self.t = 0
+        self.max_batch = max_batch
+        oh, ow, oc = model.output_shape
+        self.out_elems = oh * ow * oc
+        self._layout = [(d["name"], d["kernel"].shape, d["bias"].shape) for d in model.layers() if "kernel" in d]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            L.lib.srcfd_trainer_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def forward_backward(self, x, y, global_batch: Optional[int] = None) -> None:
+        """Accumulates this rank's gradient of the GLOBAL mean-squared error into self.grads."""
+        import torch
+        n = int(x.shape[0])
+        gb = global_batch if global_batch is not None else n
+        st = torch.cuda.current_stream(self.device)
+        L.check(L.lib.srcfd_trainer_forward_backward(
+            self._h, C.c_void_p(self.params.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), n,
+            C.c_float(1.0 / (gb * self.out_elems)), C.c_void_p(self.grads.data_ptr()), C.c_void_p(self.sse.data_ptr()),
+            C.c_void_p(st.cuda_stream)))
+
+    def apply_adam(self) -> None:
+        import torch
+        self.t += 1
+        st = torch.cuda.current_stream(self.device)
+        L.check(L.lib.srcfd_adam_step(C.c_void_p(self.params.data_ptr()), C.c_void_p(self.grads.data_ptr()), C.c_void_p(self.m.data_ptr()),
+                                      C.c_void_p(self.v.data_ptr()), self.n_params, self.t, C.c_float(self.lr), C.c_float(self.beta1),
+                                      C.c_float(self.beta2), C.c_float(self.eps), C.c_void_p(st.cuda_stream)))
+
+    def step(self, x, y, global_batch: Optional[int] = None) -> float:
+        """One optimisation step on this rank's micro-batch (contiguous float32 CUDA tensors).  Returns
+        the global mean-squared error of the batch (like Keras' `recon_loss`)."""
+        import torch
+        import torch.distributed as dist
+        n = int(x.shape[0])
+        w = world_size()
+        if global_batch is None:
+            if w > 1:
+                cnt = torch.tensor([n], dtype=torch.int64, device=self.device)
+                dist.all_reduce(cnt)
+                global_batch = int(cnt.item())
+            else:
+                global_batch = n
+        self.grads.zero_()
+        self.sse.zero_()
+        if n:
+            self.forward_backward(x, y, global_batch)
+        allreduce_sum_(self.grads)
+        self.apply_adam()
+        if w > 1:
+            dist.all_reduce(self.sse)
+        return float(self.sse.item()) / (global_batch * self.out_elems)
+
+    # -- weights in / out -------------------------------------------------------
+    def weights(self) -> Dict[str, np.ndarray]:
+        flat = self.params.detach().cpu().numpy()
+        out, off = {}, 0
+        for name, ks, bs in self._layout:
+            kn, bn = int(np.prod(ks)), int(np.prod(bs))
+            out[f"{name}/kernel"] = flat[off:off + kn].reshape(ks).copy(); off += kn
+            out[f"{name}/bias"] = flat[off:off + bn].reshape(bs).copy(); off += bn
+        assert off == self.n_params
+        return out
+
+    def export_model(self, device: Optional[int] = None) -> SRModel:
+        """A fresh inference handle with the trained weights (same layer graph)."""
+        w = self.weights()
+        specs = []
+        kinds = {L.LAYER_CONV2D: "conv2d", L.LAYER_CONV2D_TRANSPOSE: "conv2d_transpose", L.LAYER_DENSE: "dense",
+                 L.LAYER_FLATTEN: "flatten", L.LAYER_RESHAPE: "reshape"}
+        acts = {L.ACT_LINEAR: "linear", L.ACT_SWISH: "swish", L.ACT_RELU: "relu", L.ACT_SIGMOID: "sigmoid", L.ACT_TANH: "tanh"}
+        for d in self.model.layers():
+            s = dict(kind=kinds[d["kind"]], name=d["name"], k=d["kh"], stride=d["stride"], same=d["same"], act=acts[d["activation"]])
+            if d["kind"] == L.LAYER_RESHAPE:
+                s["shape"] = d["reshape"]
+            if "kernel" in d:
+                s["w"], s["b"] = w[f"{d['name']}/kernel"], w[f"{d['name']}/bias"]
+            specs.append(s)
+        return SRModel.from_layers(specs, self.model.input_shape, self.model.device if device is None else device)
+
+
+def fit(trainer: Trainer, x_lr: np.ndarray, x_hr: np.ndarray, epochs: int, batch_size: int = 8, seed: int = 0,
+        log_every: int = 0) -> List[float]:
+    """`model.fit(ds, epochs=...)` (sr-ae-conv.ipynb:c558-560) for host arrays; returns per-epoch mean loss."""
+    import torch
+    r, w = rank(), world_size()
+    xs = torch.from_numpy(np.ascontiguousarray(x_lr, np.float32)).to(trainer.device)
+    ys = torch.from_numpy(np.ascontiguousarray(x_hr, np.float32)).to(trainer.device)
+    history = []
+    for ep in range(epochs):
+        losses = []
+        for idx in epoch_batches(len(xs), batch_size, ep, seed, r, w):
+            sel = torch.from_numpy(np.ascontiguousarray(idx)).to(trainer.device)
+            losses.append(trainer.step(xs[sel].contiguous(), ys[sel].contiguous()))
+        history.append(float(np.mean(losses)))
+        if log_every and r == 0 and (ep + 1) % log_every == 0:
+            print(f"epoch {ep + 1}: recon_loss {history[-1]:.6f}")
+    return history
