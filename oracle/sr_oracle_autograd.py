@@ -28,15 +28,15 @@ def loss_and_grads(x: np.ndarray, y: np.ndarray, enc_w: Dict[str, np.ndarray], d
     t = torch.tensor(np.asarray(x, np.float64)).permute(0, 3, 1, 2)
     _, pt, pb = same_padding(t.shape[2], 3, 2)
     _, pl, pr = same_padding(t.shape[3], 3, 2)
-    h = F.silu(F.conv2d(F.pad(t, (pl, pr, pt, pb)), w["conv2d/kernel"].permute(3, 2, 0, 1), w["conv2d/bias"], stride=2))
-    h = F.silu(F.conv2d(h, w["conv2d_1/kernel"].permute(3, 2, 0, 1), w["conv2d_1/bias"], padding=1))
+    h = F.silu(F.conv2d(F.pad(t, (pl, pr, pt, pb)), w["conv2d/kernel"].permute(3, 2, 0, 1).contiguous(), w["conv2d/bias"], stride=2))
+    h = F.silu(F.conv2d(h, w["conv2d_1/kernel"].permute(3, 2, 0, 1).contiguous(), w["conv2d_1/bias"], padding=1))
     h = h.permute(0, 2, 3, 1).reshape(h.shape[0], -1)
     h = F.silu(h @ w["dense/kernel"] + w["dense/bias"])
     z = h @ w["latent_vector/kernel"] + w["latent_vector/bias"]
     h = F.silu(z @ w["dense_1/kernel"] + w["dense_1/bias"]).reshape(-1, 12, 12, 256).permute(0, 3, 1, 2)
     for name in DECODER_LAYERS[1:6]:
-        h = F.silu(F.conv_transpose2d(h, w[f"{name}/kernel"].permute(3, 2, 0, 1), w[f"{name}/bias"], stride=2))
-    pred = F.conv2d(h, w["output_image_400/kernel"].permute(3, 2, 0, 1), w["output_image_400/bias"], padding=1).permute(0, 2, 3, 1)
+        h = F.silu(F.conv_transpose2d(h, w[f"{name}/kernel"].permute(3, 2, 0, 1).contiguous(), w[f"{name}/bias"], stride=2))
+    pred = F.conv2d(h, w["output_image_400/kernel"].permute(3, 2, 0, 1).contiguous(), w["output_image_400/bias"], padding=1).permute(0, 2, 3, 1)
     loss = torch.mean((torch.tensor(np.asarray(y, np.float64)) - pred) ** 2)
     loss.backward()
     flat = np.concatenate([w[k].grad.numpy().reshape(-1) for k in flat_order(enc_w, dec_w)])

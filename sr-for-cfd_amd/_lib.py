@@ -44,7 +44,23 @@ def _load() -> C.CDLL:
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C sr-for-cfd_amd/csrc` (hipcc, --offload-arch=gfx950). There is no CPU fallback.")
+    _share_hip_runtime_with_torch()
     return C.CDLL(LIB_PATH)
+
+
+def _share_hip_runtime_with_torch() -> None:
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so (soname
+    libamdhip64.so.7) and links it by the unversioned name; libsrcfd needs `libamdhip64.so.7`.
+    Whichever loads first decides whether the second resolves to the same object: torch first is
+    fine, libsrcfd first would bring in /opt/rocm's copy and torch then loads a second runtime that
+    finds no devices.  So when torch is installed (not necessarily imported), map its copy first."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
 
 
 lib = _load()

@@ -43,6 +43,8 @@ struct Model {
 
   float* buf[2] = {nullptr, nullptr};
   int ws_chunk = 0;
+  float* d_splitk = nullptr;  // split-K slabs of the skinny f32 GEMMs
+  size_t splitk_floats = 0;
   float* d_x_stage = nullptr;
   float* d_y_stage = nullptr;
   float* d_aff = nullptr;

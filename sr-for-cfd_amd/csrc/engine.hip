@@ -143,7 +143,7 @@ void Model::drop_graph() {
 
 void Model::free_workspace() {
   for (int i = 0; i < 2; ++i) if (buf[i]) { (void)hipFree(buf[i]); buf[i] = nullptr; }
-  for (void* p : {(void*)d_x_stage, (void*)d_y_stage, (void*)d_aff, (void*)d_nonfinite}) if (p) (void)hipFree(p);
+  for (void* p : {(void*)d_x_stage, (void*)d_y_stage, (void*)d_aff, (void*)d_nonfinite, (void*)d_splitk}) if (p) (void)hipFree(p);
   d_x_stage = d_y_stage = nullptr; d_aff = nullptr; d_nonfinite = nullptr;
   ws_chunk = 0; stage_chunk = 0;
 }
@@ -182,6 +182,15 @@ int Model::ensure_workspace(int n) {
   ws_chunk = 0;
   size_t bytes = (size_t)chunk * max_act_elems() * sizeof(float);
   for (int i = 0; i < 2; ++i) HIPCHECK(hipMalloc(&buf[i], bytes));
+  size_t need = 0;
+  for (const Op& op : ops) {
+    GemmDesc d = op.d;
+    d.M = chunk * d.MH * d.MW;
+    need = std::max(need, gemm_splitk_ws_floats(d));
+  }
+  if (d_splitk) { HIPCHECK(hipFree(d_splitk)); d_splitk = nullptr; }
+  splitk_floats = need;
+  if (need) HIPCHECK(hipMalloc(&d_splitk, need * sizeof(float)));
   ws_chunk = chunk;
   return SRCFD_OK;
 }
@@ -226,7 +235,7 @@ int Model::forward_generic(const float* x_dev, int n, const float* aff_in, const
     float* Y = buf[cur ^ 1];
     const float* B = d_pack + op.w_off;
     const float* bias = d_pack + op.b_off;
-    rc = launch(op.name.c_str(), s, [&] { return naive ? launch_gemm_naive(d, X, B, bias, Y, s) : launch_gemm_mfma(d, X, B, bias, Y, s); });
+    rc = launch(op.name.c_str(), s, [&] { return naive ? launch_gemm_naive(d, X, B, bias, Y, s) : launch_gemm_mfma(d, X, B, bias, Y, s, d_splitk, splitk_floats); });
     if (rc) return rc;
   }
   cur ^= 1;

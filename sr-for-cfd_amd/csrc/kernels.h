@@ -22,7 +22,11 @@ struct GemmDesc {
 };
 
 hipError_t launch_gemm_naive(const GemmDesc& d, const float* X, const float* B, const float* bias, float* Y, hipStream_t s);
-hipError_t launch_gemm_mfma(const GemmDesc& d, const float* X, const float* B, const float* bias, float* Y, hipStream_t s);
+// ws: optional split-K scratch (gemm_splitk_ws_floats(d) floats); without it the launch never splits.
+hipError_t launch_gemm_mfma(const GemmDesc& d, const float* X, const float* B, const float* bias, float* Y, hipStream_t s,
+                            float* ws = nullptr, size_t ws_floats = 0);
+int gemm_splitk_splits(const GemmDesc& d, int* kchunk_out);
+size_t gemm_splitk_ws_floats(const GemmDesc& d);
 hipError_t launch_standardize(const float* x, float* y, const float* affine, int per_sample, int64_t total, hipStream_t s);
 hipError_t launch_finalize(const float* y, void* out, int out_dtype, const float* affine, int per_sample, int64_t total,
                            int nan_guard, unsigned long long* nonfinite, hipStream_t s);

@@ -13,6 +13,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "kernels.h"
 
 namespace srcfd {
@@ -92,11 +94,15 @@ __global__ void __launch_bounds__(256) gemm_naive_f32(GemmDesc d, const float* _
 // ---------------------------------------------------------------------------
 constexpr int BM = 128, BK = 16, LDA = BK + 1;
 
-template <int NB, bool VEC>
+// VEC 0: scalar gather (any CI); 1: CI % 16 == 0 (a 16-deep K slab sits inside one tap);
+// 2: CI % 4 == 0 (each 16-byte group sits inside one tap).
+// The next slab's global loads are issued into registers before the current slab's MFMAs and
+// parked in LDS after them, so HBM/L2 latency overlaps the matrix work (one LDS stage).
+template <int NB, int VEC>
 __global__ void __launch_bounds__(256) gemm_mfma_f32(GemmDesc d, const float* __restrict__ X,
                                                       const float* __restrict__ B,
                                                       const float* __restrict__ bias,
-                                                      float* __restrict__ Y) {
+                                                      float* __restrict__ Y, float* __restrict__ ws, int kchunk) {
   constexpr int BN = 32 * NB;
   __shared__ float As[BM * LDA];
   __shared__ float Bs[BK * BN];
@@ -118,24 +124,27 @@ __global__ void __launch_bounds__(256) gemm_mfma_f32(GemmDesc d, const float* __
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-  const int K = d.K;
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    // ---- stage A tile [BM][BK] ----
+  // split-K (ws != nullptr): this block reduces k in [z*kchunk, (z+1)*kchunk) and leaves raw partial
+  // sums in ws[z][m][n]; splitk_finish_f32 adds the slabs in z order (reproducible), bias and activation.
+  const int K = ws ? min(d.K, ((int)blockIdx.z + 1) * kchunk) : d.K;
+  const int kbeg = ws ? (int)blockIdx.z * kchunk : 0;
+
+  float ra[8], rb[2 * NB];
+  auto fetch = [&](int k0) {
     if (VEC) {
-      int tap = k0 / d.CI, ci0 = k0 - tap * d.CI;
-      int ty = tap / d.TX, tx = tap - ty * d.TX;
+      const int c4 = tid & 3, k = k0 + 4 * c4;
+      const int tap = k / d.CI, ci0 = k - tap * d.CI, ty = tap / d.TX, tx = tap - ty * d.TX;
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        int row = (tid >> 2) + 64 * j, c4 = tid & 3;
+        const int row = (tid >> 2) + 64 * j;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        int img = row_img[row];
-        if (img >= 0) {
+        const int img = row_img[row];
+        if (img >= 0 && k < K) {
           int iy = row_my[row] * d.ay + ty * d.by + d.cy, ix = row_mx[row] * d.ax + tx * d.bx + d.cx;
           if (iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW)
-            v = *reinterpret_cast<const float4*>(X + (((int64_t)img * d.IH + iy) * d.IW + ix) * d.CI + ci0 + c4 * 4);
+            v = *reinterpret_cast<const float4*>(X + (((int64_t)img * d.IH + iy) * d.IW + ix) * d.CI + ci0);
         }
-        float* dst = As + row * LDA + c4 * 4;
-        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        ra[4 * j] = v.x; ra[4 * j + 1] = v.y; ra[4 * j + 2] = v.z; ra[4 * j + 3] = v.w;
       }
     } else {
 #pragma unroll
@@ -150,16 +159,36 @@ __global__ void __launch_bounds__(256) gemm_mfma_f32(GemmDesc d, const float* __
           if (iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW)
             v = X[(((int64_t)img * d.IH + iy) * d.IW + ix) * d.CI + ci];
         }
-        As[row * LDA + kk] = v;
+        ra[j] = v;
       }
     }
-    // ---- stage B tile [BK][BN] (B is zero-padded to Npad columns) ----
+    // B tile [BK][BN] (B is zero-padded to Npad columns)
 #pragma unroll
-    for (int e = tid; e < BK * BN; e += 256) {
-      int kk = e / BN, c = e - kk * BN, k = k0 + kk;
-      Bs[e] = (k < K) ? B[(int64_t)k * d.Npad + n0 + c] : 0.f;
+    for (int j = 0; j < 2 * NB; ++j) {
+      int e = tid + 256 * j, kk = e / BN, c = e - kk * BN, k = k0 + kk;
+      rb[j] = (k < K) ? B[(int64_t)k * d.Npad + n0 + c] : 0.f;
     }
+  };
+  auto park = [&]() {
+    if (VEC) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        float* dst = As + ((tid >> 2) + 64 * j) * LDA + (tid & 3) * 4;
+        dst[0] = ra[4 * j]; dst[1] = ra[4 * j + 1]; dst[2] = ra[4 * j + 2]; dst[3] = ra[4 * j + 3];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { int e = tid + 256 * j; As[(e >> 4) * LDA + (e & 15)] = ra[j]; }
+    }
+#pragma unroll
+    for (int j = 0; j < 2 * NB; ++j) Bs[tid + 256 * j] = rb[j];
+  };
+
+  if (kbeg < K) fetch(kbeg);
+  for (int k0 = kbeg; k0 < K; k0 += BK) {
+    park();
     __syncthreads();
+    if (k0 + BK < K) fetch(k0 + BK);
     const float* ap = As + (wave * 32 + (lane & 31)) * LDA + (lane >> 5);
     const float* bp = Bs + (lane >> 5) * BN + (lane & 31);
 #pragma unroll
@@ -171,6 +200,19 @@ __global__ void __launch_bounds__(256) gemm_mfma_f32(GemmDesc d, const float* __
     __syncthreads();
   }
 
+  if (ws) {
+    float* slab = ws + (int64_t)blockIdx.z * d.M * d.Npad;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      int n = n0 + 32 * i + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < d.M) slab[(int64_t)m * d.Npad + n] = acc[i][r];
+      }
+    }
+    return;
+  }
   // ---- epilogue: bias + activation + (pixel-shuffle) store ----
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
@@ -188,6 +230,28 @@ __global__ void __launch_bounds__(256) gemm_mfma_f32(GemmDesc d, const float* __
       Y[(((int64_t)img * d.OH + oy) * d.OW + ox) * d.OC + co] = act_apply_precise(acc[i][r] + bv, d.act);
     }
   }
+}
+
+__global__ void __launch_bounds__(256) splitk_finish_f32(GemmDesc d, const float* __restrict__ ws, int splits,
+                                                          const float* __restrict__ bias, float* __restrict__ Y, int groups) {
+  // (256 / groups) outputs x `groups` slab groups per block: group g adds slabs g, g+groups, ... and the
+  // groups are added in order, so the result does not depend on scheduling.
+  __shared__ float red[256];
+  const int epb = 256 / groups, e = threadIdx.x % epb, g = threadIdx.x / epb;
+  const int64_t idx = (int64_t)blockIdx.x * epb + e, total = (int64_t)d.M * d.N;
+  int m = 0, n = 0;
+  float acc = 0.f;
+  if (idx < total) {
+    m = (int)(idx / d.N); n = (int)(idx - (int64_t)m * d.N);
+    for (int z = g; z < splits; z += groups) acc += ws[((int64_t)z * d.M + m) * d.Npad + n];
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  if (g != 0 || idx >= total) return;
+  for (int q = 1; q < groups; ++q) acc += red[q * epb + e];
+  int img, my, mx;
+  row_decode(d, m, img, my, mx);
+  Y[out_offset(d, img, my, mx, n)] = act_apply_precise(acc + bias[n], d.act);
 }
 
 // ---------------------------------------------------------------------------
@@ -225,6 +289,44 @@ __global__ void __launch_bounds__(256) conv_n1_f32(GemmDesc d, const float* __re
     }
   }
   Y[out_offset(d, img, my, mx, 0)] = act_apply_precise(acc, d.act);
+}
+
+// single-input-channel conv with <= 8 output channels (the data gradient of `output_image_400`:
+// a 3x3 1->8 flipped-tap conv over 400x400): one thread per pixel, 8 accumulators, two 16-byte stores.
+__global__ void __launch_bounds__(256) conv_ci1_f32(GemmDesc d, const float* __restrict__ X, const float* __restrict__ B,
+                                                     const float* __restrict__ bias, float* __restrict__ Y) {
+  __shared__ float w[64 * 8];
+  for (int i = threadIdx.x; i < d.K * 8; i += 256) { int k = i >> 3, c = i & 7; w[i] = c < d.N ? B[(int64_t)k * d.Npad + c] : 0.f; }
+  __syncthreads();
+  int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (m >= d.M) return;
+  int img, my, mx;
+  row_decode(d, (int)m, img, my, mx);
+  float acc[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) acc[c] = c < d.N ? bias[c] : 0.f;
+  for (int ty = 0; ty < d.TY; ++ty) {
+    int iy = my * d.ay + ty * d.by + d.cy;
+    if (iy < 0 || iy >= d.IH) continue;
+    for (int tx = 0; tx < d.TX; ++tx) {
+      int ix = mx * d.ax + tx * d.bx + d.cx;
+      if (ix < 0 || ix >= d.IW) continue;
+      float v = X[((int64_t)img * d.IH + iy) * d.IW + ix];
+      const float* wp = w + (ty * d.TX + tx) * 8;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) acc[c] = fmaf(v, wp[c], acc[c]);
+    }
+  }
+  float* yp = Y + out_offset(d, img, my, mx, 0);
+  if (d.N == 8 && (d.OC & 3) == 0) {
+    reinterpret_cast<float4*>(yp)[0] = make_float4(act_apply_precise(acc[0], d.act), act_apply_precise(acc[1], d.act),
+                                                    act_apply_precise(acc[2], d.act), act_apply_precise(acc[3], d.act));
+    reinterpret_cast<float4*>(yp)[1] = make_float4(act_apply_precise(acc[4], d.act), act_apply_precise(acc[5], d.act),
+                                                    act_apply_precise(acc[6], d.act), act_apply_precise(acc[7], d.act));
+  } else {
+#pragma unroll
+    for (int c = 0; c < 8; ++c) if (c < d.N) yp[c] = act_apply_precise(acc[c], d.act);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -286,20 +388,53 @@ hipError_t launch_gemm_naive(const GemmDesc& d, const float* X, const float* B, 
   return hipGetLastError();
 }
 
-hipError_t launch_gemm_mfma(const GemmDesc& d, const float* X, const float* B, const float* bias, float* Y, hipStream_t s) {
+// Skinny problems (few output tiles, long K: the Dense layers, and every layer at training batch
+// sizes) are cut along K so that the weight matrix is streamed by >= 256 blocks instead of 1-6.
+int gemm_splitk_splits(const GemmDesc& d, int* kchunk_out) {
+  int nb = (d.Npad % 128 == 0) ? 4 : ((d.Npad % 64 == 0) ? 2 : 1);
+  int64_t tiles = (int64_t)((d.M + BM - 1) / BM) * (d.Npad / (32 * nb));
+  if (kchunk_out) *kchunk_out = d.K;
+  if (tiles >= 128 || d.K < 256 || tiles == 0) return 1;
+  int want = (int)std::min<int64_t>(std::min<int64_t>((512 + tiles - 1) / tiles, d.K / 64), 256);
+  if (want <= 1) return 1;
+  int kchunk = ((d.K + want - 1) / want + BK - 1) / BK * BK;
+  if (kchunk_out) *kchunk_out = kchunk;
+  return (d.K + kchunk - 1) / kchunk;
+}
+
+size_t gemm_splitk_ws_floats(const GemmDesc& d) {
+  int splits = gemm_splitk_splits(d, nullptr);
+  return splits > 1 ? (size_t)splits * d.M * d.Npad : 0;
+}
+
+hipError_t launch_gemm_mfma(const GemmDesc& d, const float* X, const float* B, const float* bias, float* Y, hipStream_t s, float* ws,
+                            size_t ws_floats) {
   if (d.M == 0 || d.N == 0) return hipSuccess;
   if (d.N == 1 && d.K <= 512 && d.nphx == 1) {
     hipLaunchKernelGGL(conv_n1_f32, dim3((unsigned)((d.M + 255) / 256)), dim3(256), 0, s, d, X, B, bias, Y);
     return hipGetLastError();
   }
-  bool vec = (d.CI % 16 == 0) && d.K > 0;
+  if (d.CI == 1 && d.N <= 8 && d.K <= 64 && d.nphx == 1 && d.CO == d.N) {
+    hipLaunchKernelGGL(conv_ci1_f32, dim3((unsigned)((d.M + 255) / 256)), dim3(256), 0, s, d, X, B, bias, Y);
+    return hipGetLastError();
+  }
+  const int vec = d.K <= 0 ? 0 : (d.CI % 16 == 0 ? 1 : (d.CI % 4 == 0 ? 2 : 0));
   int nb = (d.Npad % 128 == 0) ? 4 : ((d.Npad % 64 == 0) ? 2 : 1);
-  dim3 grid((d.M + BM - 1) / BM, d.Npad / (32 * nb));
-#define GO(NBV, VECV) hipLaunchKernelGGL((gemm_mfma_f32<NBV, VECV>), grid, dim3(256), 0, s, d, X, B, bias, Y)
-  if (nb == 4) { if (vec) GO(4, true); else GO(4, false); }
-  else if (nb == 2) { if (vec) GO(2, true); else GO(2, false); }
-  else { if (vec) GO(1, true); else GO(1, false); }
+  int kchunk = d.K;
+  int splits = ws ? gemm_splitk_splits(d, &kchunk) : 1;
+  if (splits > 1 && (size_t)splits * d.M * d.Npad > ws_floats) splits = 1;
+  float* wsp = splits > 1 ? ws : nullptr;
+  dim3 grid((d.M + BM - 1) / BM, d.Npad / (32 * nb), splits);
+#define GO(NBV, VECV) hipLaunchKernelGGL((gemm_mfma_f32<NBV, VECV>), grid, dim3(256), 0, s, d, X, B, bias, Y, wsp, kchunk)
+  if (nb == 4) { if (vec == 1) GO(4, 1); else if (vec == 2) GO(4, 2); else GO(4, 0); }
+  else if (nb == 2) { if (vec == 1) GO(2, 1); else if (vec == 2) GO(2, 2); else GO(2, 0); }
+  else { if (vec == 1) GO(1, 1); else if (vec == 2) GO(1, 2); else GO(1, 0); }
 #undef GO
+  if (splits > 1) {
+    int64_t total = (int64_t)d.M * d.N;
+    const int groups = (splits >= 32 && total < 65536) ? 8 : 1, epb = 256 / groups;
+    hipLaunchKernelGGL(splitk_finish_f32, dim3((unsigned)((total + epb - 1) / epb)), dim3(256), 0, s, d, wsp, splits, bias, Y, groups);
+  }
   return hipGetLastError();
 }
 

@@ -75,12 +75,17 @@ __global__ void __launch_bounds__(256) mse_grad_f32(const float* __restrict__ pr
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
-__global__ void sum_partials_f64(const double* __restrict__ partial, int n, double* __restrict__ out) {
-  if (threadIdx.x == 0 && blockIdx.x == 0) {
-    double s = 0.0;
-    for (int i = 0; i < n; ++i) s += partial[i];
-    *out += s;
+__global__ void __launch_bounds__(256) sum_partials_f64(const double* __restrict__ partial, int n, double* __restrict__ out) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
   }
+  if (threadIdx.x == 0) *out += red[0];
 }
 
 // dst[i] = map[i] > 0 ? src[map[i]-1] : 0   (flat params -> packed operand buffers)
@@ -104,76 +109,297 @@ __global__ void __launch_bounds__(256) adam_f32(float* __restrict__ p, const flo
 
 // ---------------------------------------------------------------------------
 // weight gradient: dB[k][n] = sum_m A[m][k] * dZ[m][n], plus the bias row k == K (A = 1).
-// One wave = one 32(k) x 32(n) tile over one slice of the rows; v_mfma_f32_32x32x2_f32 with the
-// row index m as the MFMA's reduction dimension.  Partial tiles go to part[slice][k][n] and are
-// summed in slice order by wgrad_finish (reproducible), which also scatters into the flat gradient.
+// The reduction runs over the rows m (pixels), so m is the MFMA's k dimension:
+// v_mfma_f32_32x32x2_f32 with a = A[m..m+1][32 k's], b = dZ[m..m+1][32 n's].
+// A block owns KG x NG tiles of 32x32 (k x n) and one slice of the rows; it walks the slice in
+// chunks of 64 rows: the implicit-GEMM A tile [64][32 KG] and the dZ tile [64][32 NG] are gathered
+// with 16-byte loads into registers one chunk ahead, parked in LDS, and consumed by the 4 waves
+// (tile t -> wave t % 4; with fewer than 4 tiles the waves split the rows of the chunk instead and
+// add their accumulators through LDS in wave order).  Slabs part[slice][k][n] are summed in slab order by wgrad_finish
+// (reproducible: no float atomics), which also scatters into the flat gradient.
 // ---------------------------------------------------------------------------
+constexpr int WG_RC = 64;
+
+template <int KG, int NG>
 __global__ void __launch_bounds__(256) wgrad_f32(GemmDesc d, const float* __restrict__ X, const float* __restrict__ dZ, float* __restrict__ part,
-                                                  int rows_per_slice, int nslices, int ktiles) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int slice = blockIdx.y * 4 + wave;
-  if (slice >= nslices) return;
-  const int kt = blockIdx.x % ktiles, nt = blockIdx.x / ktiles;
-  const int l31 = lane & 31, hh = lane >> 5;
-  // this lane's A column (k) and dZ column (n)
-  const int k = kt * 32 + l31;
-  const bool is_bias = k == d.K, k_ok = k < d.K;
-  int ty = 0, tx = 0, ci = 0;
-  if (k_ok) { int tap = k / d.CI; ci = k - tap * d.CI; ty = tap / d.TX; tx = tap - ty * d.TX; }
-  const int n = nt * 32 + l31;
-  const bool n_ok = n < d.N;
-  int py = 0, px = 0, co = 0;
-  if (n_ok) { int ph = n / d.CO; co = n - ph * d.CO; py = ph / d.nphx; px = ph - py * d.nphx; }
-  f32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                                                  int rows_per_slice, int kblocks, int ktiles, int ntiles) {
+  constexpr int KT = 32 * KG, NT = 32 * NG, T = KG * NG, RS = T >= 4 ? 1 : 4 / T, TPW = T >= 4 ? T / 4 : 1;
+  constexpr int SA = KG == 2 ? 96 : 32, SB = NG == 4 ? 160 : (NG == 2 ? 96 : 32);  // row strides = 32 mod 64: the two row halves of a
+  __shared__ float As[WG_RC * SA];                                                  // wave hit disjoint banks
+  __shared__ float Bs[WG_RC * SB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hh = lane >> 5;
+  const int kb = blockIdx.x % kblocks, nblk = blockIdx.x / kblocks, slice = blockIdx.y;
+  const int kbase = kb * KT, nbase = nblk * NT;
   const int m_beg = slice * rows_per_slice, m_end = min(d.M, m_beg + rows_per_slice);
   const int per = d.MH * d.MW;
-  for (int m0 = m_beg; m0 < m_end; m0 += 2) {
-    const int m = m0 + hh;
-    float a = 0.f, b = 0.f;
-    if (m < m_end) {
-      int img = m / per, r = m - img * per, my = r / d.MW, mx = r - my * d.MW;
-      if (is_bias) a = 1.f;
-      else if (k_ok) {
-        int iy = my * d.ay + ty * d.by + d.cy, ix = mx * d.ax + tx * d.bx + d.cx;
-        if (iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW) a = X[(((int64_t)img * d.IH + iy) * d.IW + ix) * d.CI + ci];
+  const bool vecA = (d.CI & 3) == 0, vecB = (d.CO & 3) == 0;
+
+  // ---- this thread's fixed column in the A / dZ tiles ----
+  const int a_per_row = vecA ? KT / 4 : KT, a_rows_pass = 256 / a_per_row;
+  const int a_col = (tid % a_per_row) * (vecA ? 4 : 1), a_row0 = tid / a_per_row;
+  const int ak = kbase + a_col;
+  int a_ty = 0, a_tx = 0, a_ci = 0;
+  if (ak < d.K) { int tap = ak / d.CI; a_ci = ak - tap * d.CI; a_ty = tap / d.TX; a_tx = tap - a_ty * d.TX; }
+  const int b_per_row = vecB ? NT / 4 : NT, b_rows_pass = 256 / b_per_row;
+  const int b_col = (tid % b_per_row) * (vecB ? 4 : 1), b_row0 = tid / b_per_row;
+  const int bn = nbase + b_col;
+  int b_py = 0, b_px = 0, b_co = 0;
+  if (bn < d.N) { int ph = bn / d.CO; b_co = bn - ph * d.CO; b_py = ph / d.nphx; b_px = ph - b_py * d.nphx; }
+
+  float ra[KG * 8], rb[NG * 8];
+  auto fetch = [&](int m0) {
+    if (vecA) {
+#pragma unroll
+      for (int j = 0; j < KG * 2; ++j) {
+        int m = m0 + a_row0 + a_rows_pass * j;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < m_end) {
+          if (ak < d.K) {
+            int img = m / per, r = m - img * per, my = r / d.MW, mx = r - my * d.MW;
+            int iy = my * d.ay + a_ty * d.by + d.cy, ix = mx * d.ax + a_tx * d.bx + d.cx;
+            if (iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW)
+              v = *reinterpret_cast<const float4*>(X + (((int64_t)img * d.IH + iy) * d.IW + ix) * d.CI + a_ci);
+          } else if (ak == d.K) v.x = 1.f;
+        }
+        ra[4 * j] = v.x; ra[4 * j + 1] = v.y; ra[4 * j + 2] = v.z; ra[4 * j + 3] = v.w;
       }
-      if (n_ok) {
-        int oy = my * d.os + d.oy0 + py, ox = mx * d.os + d.ox0 + px;
-        b = dZ[(((int64_t)img * d.OH + oy) * d.OW + ox) * d.OC + co];
+    } else {
+#pragma unroll
+      for (int j = 0; j < KG * 8; ++j) {
+        int m = m0 + a_row0 + a_rows_pass * j;
+        float v = 0.f;
+        if (m < m_end) {
+          if (ak < d.K) {
+            int img = m / per, r = m - img * per, my = r / d.MW, mx = r - my * d.MW;
+            int iy = my * d.ay + a_ty * d.by + d.cy, ix = mx * d.ax + a_tx * d.bx + d.cx;
+            if (iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW) v = X[(((int64_t)img * d.IH + iy) * d.IW + ix) * d.CI + a_ci];
+          } else if (ak == d.K) v = 1.f;
+        }
+        ra[j] = v;
       }
     }
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    if (vecB) {
+#pragma unroll
+      for (int j = 0; j < NG * 2; ++j) {
+        int m = m0 + b_row0 + b_rows_pass * j;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < m_end && bn < d.N) {
+          int img = m / per, r = m - img * per, my = r / d.MW, mx = r - my * d.MW;
+          int oy = my * d.os + d.oy0 + b_py, ox = mx * d.os + d.ox0 + b_px;
+          v = *reinterpret_cast<const float4*>(dZ + (((int64_t)img * d.OH + oy) * d.OW + ox) * d.OC + b_co);
+        }
+        rb[4 * j] = v.x; rb[4 * j + 1] = v.y; rb[4 * j + 2] = v.z; rb[4 * j + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NG * 8; ++j) {
+        int m = m0 + b_row0 + b_rows_pass * j;
+        float v = 0.f;
+        if (m < m_end && bn < d.N) {
+          int img = m / per, r = m - img * per, my = r / d.MW, mx = r - my * d.MW;
+          int oy = my * d.os + d.oy0 + b_py, ox = mx * d.os + d.ox0 + b_px;
+          v = dZ[(((int64_t)img * d.OH + oy) * d.OW + ox) * d.OC + b_co];
+        }
+        rb[j] = v;
+      }
+    }
+  };
+  auto park = [&]() {
+    if (vecA) {
+#pragma unroll
+      for (int j = 0; j < KG * 2; ++j)
+        *reinterpret_cast<float4*>(As + (a_row0 + a_rows_pass * j) * SA + a_col) = make_float4(ra[4 * j], ra[4 * j + 1], ra[4 * j + 2], ra[4 * j + 3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < KG * 8; ++j) As[(a_row0 + a_rows_pass * j) * SA + a_col] = ra[j];
+    }
+    if (vecB) {
+#pragma unroll
+      for (int j = 0; j < NG * 2; ++j)
+        *reinterpret_cast<float4*>(Bs + (b_row0 + b_rows_pass * j) * SB + b_col) = make_float4(rb[4 * j], rb[4 * j + 1], rb[4 * j + 2], rb[4 * j + 3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NG * 8; ++j) Bs[(b_row0 + b_rows_pass * j) * SB + b_col] = rb[j];
+    }
+  };
+
+  // ---- this wave's tiles / row share ----
+  const int t0 = T >= 4 ? wave : wave % T, rsub = T >= 4 ? 0 : wave / T;
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int i = 0; i < TPW; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  fetch(m_beg);
+  for (int m0 = m_beg; m0 < m_end; m0 += WG_RC) {
+    park();
+    __syncthreads();
+    if (m0 + WG_RC < m_end) fetch(m0 + WG_RC);
+    const int valid = min(WG_RC, m_end - m0);
+    const int steps = (valid + 1) >> 1;                 // row pairs holding data
+    const int per_w = (steps + RS - 1) / RS;
+    const int s_beg = rsub * per_w, s_end = min(steps, s_beg + per_w);
+    for (int st = s_beg; st < s_end; ++st) {
+      const int r = 2 * st + hh;
+#pragma unroll
+      for (int i = 0; i < TPW; ++i) {
+        const int t = t0 + 4 * i, kt = t / NG, nt = t - kt * NG;
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(As[r * SA + kt * 32 + l31], Bs[r * SB + nt * 32 + l31], acc[i], 0, 0, 0);
+      }
+    }
+    __syncthreads();
   }
-  // D[row = k in tile][col = n in tile]
+  // with fewer than 4 tiles the waves of one tile hold partial sums over disjoint rows: add them in wave order
+  if (RS > 1) {
+    __shared__ float red[(RS > 1 ? 4 - T : 1) * 1024];
+    if (rsub > 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[(wave - T) * 1024 + r * 64 + lane] = acc[0][r];
+    }
+    __syncthreads();
+    if (rsub > 0) return;
+    for (int w = wave + T; w < 4; w += T)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[0][r] += red[(w - T) * 1024 + r * 64 + lane];
+  }
+  // D[row = k in tile][col = n in tile] -> slab of this slice
   float* out = part + ((int64_t)slice * (d.K + 1)) * d.Npad;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    int kk = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-    if (kk <= d.K && n_ok) out[(int64_t)kk * d.Npad + n] = acc[r];
+  for (int i = 0; i < TPW; ++i) {
+    const int t = t0 + 4 * i, kt = kb * KG + t / NG, nt = nblk * NG + t % NG;
+    if (kt >= ktiles || nt >= ntiles) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int kk = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      if (kk <= d.K) out[(int64_t)kk * d.Npad + nt * 32 + l31] = acc[i][r];
+    }
   }
+}
+
+// Single-output-channel 3x3 x 8-channel layer (`output_image_400`): N = 1 would leave 31/32 of the MFMA
+// columns empty, so each thread walks its pixels with 73 f32 accumulators (72 weights + bias); lanes are
+// folded with DPP-free shuffles, waves through LDS, and every block writes one slab (column 0 only).
+__global__ void __launch_bounds__(256) wgrad_n1_k72_f32(GemmDesc d, const float* __restrict__ X, const float* __restrict__ dZ,
+                                                         float* __restrict__ part, int rows_per_block) {
+  __shared__ float red[4][73];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m_beg = blockIdx.x * rows_per_block, m_end = min(d.M, m_beg + rows_per_block);
+  const int per = d.MH * d.MW;
+  float acc[73];
+#pragma unroll
+  for (int i = 0; i < 73; ++i) acc[i] = 0.f;
+  for (int m = m_beg + tid; m < m_end; m += 256) {
+    int img = m / per, r = m - img * per, my = r / d.MW, mx = r - my * d.MW;
+    const float g = dZ[(((int64_t)img * d.OH + my * d.os + d.oy0) * d.OW + mx * d.os + d.ox0) * d.OC];
+    acc[72] += g;
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty) {
+      int iy = my * d.ay + ty * d.by + d.cy;
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) {
+        int ix = mx * d.ax + tx * d.bx + d.cx;
+        if (iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW) {
+          const float4* xp = reinterpret_cast<const float4*>(X + (((int64_t)img * d.IH + iy) * d.IW + ix) * 8);
+          float4 a = xp[0], b = xp[1];
+          float* ap = acc + (ty * 3 + tx) * 8;
+          ap[0] = fmaf(a.x, g, ap[0]); ap[1] = fmaf(a.y, g, ap[1]); ap[2] = fmaf(a.z, g, ap[2]); ap[3] = fmaf(a.w, g, ap[3]);
+          ap[4] = fmaf(b.x, g, ap[4]); ap[5] = fmaf(b.y, g, ap[5]); ap[6] = fmaf(b.z, g, ap[6]); ap[7] = fmaf(b.w, g, ap[7]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 73; ++i) {
+    float v = acc[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (lane == 0) red[wave][i] = v;
+  }
+  __syncthreads();
+  if (tid < 73) part[((int64_t)blockIdx.x * 73 + tid) * d.Npad] = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+}
+
+static bool wgrad_is_n1_k72(const GemmDesc& d) { return d.N == 1 && d.TY == 3 && d.TX == 3 && d.CI == 8 && d.nphx == 1; }
+
+struct WgradPlan { int KG, NG, kblocks, nblocks, ktiles, ntiles, nslices, rps; };
+
+static WgradPlan wgrad_plan(const GemmDesc& d) {
+  WgradPlan p;
+  if (wgrad_is_n1_k72(d)) {
+    p = WgradPlan{0, 0, 1, 1, 3, 1, 0, 0};
+    p.nslices = (int)std::max<int64_t>(1, std::min<int64_t>(256, ((int64_t)d.M + 1023) / 1024));
+    p.rps = (d.M + p.nslices - 1) / p.nslices;
+    p.nslices = std::max(1, (d.M + p.rps - 1) / p.rps);
+    return p;
+  }
+  p.ktiles = (d.K + 1 + 31) / 32;
+  p.ntiles = d.Npad / 32;
+  p.KG = p.ktiles >= 2 ? 2 : 1;
+  p.NG = p.ntiles >= 3 ? 4 : (p.ntiles == 2 ? 2 : 1);
+  p.kblocks = (p.ktiles + p.KG - 1) / p.KG;
+  p.nblocks = (p.ntiles + p.NG - 1) / p.NG;
+  const int64_t blocks = (int64_t)p.kblocks * p.nblocks, chunks = std::max<int64_t>(1, ((int64_t)d.M + WG_RC - 1) / WG_RC);
+  int64_t want = std::max<int64_t>(1, std::min<int64_t>(chunks, 512 / blocks));
+  p.rps = (int)(((chunks + want - 1) / want) * WG_RC);
+  p.nslices = (int)std::max<int64_t>(1, ((int64_t)d.M + p.rps - 1) / p.rps);
+  return p;
+}
+
+static void launch_wgrad(const GemmDesc& d, const WgradPlan& p, const float* X, const float* dZ, float* part, hipStream_t s) {
+  if (p.KG == 0) {
+    hipLaunchKernelGGL(wgrad_n1_k72_f32, dim3(p.nslices), dim3(256), 0, s, d, X, dZ, part, p.rps);
+    return;
+  }
+  dim3 grid(p.kblocks * p.nblocks, p.nslices);
+#define GO(KGV, NGV) hipLaunchKernelGGL((wgrad_f32<KGV, NGV>), grid, dim3(256), 0, s, d, X, dZ, part, p.rps, p.kblocks, p.ktiles, p.ntiles)
+  if (p.KG == 2) { if (p.NG == 4) GO(2, 4); else if (p.NG == 2) GO(2, 2); else GO(2, 1); }
+  else { if (p.NG == 4) GO(1, 4); else if (p.NG == 2) GO(1, 2); else GO(1, 1); }
+#undef GO
 }
 
 // grads[map[i]-1] += sum_slices part[slice][i]   for the (K+1) x Npad elements of one op.  In the bias
 // row of a merged-phase op (kernel == stride transposed conv) the N/CO phase columns of one channel
 // all map to the same parameter: the thread of phase 0 sums them in phase order (no atomics).
 __global__ void __launch_bounds__(256) wgrad_finish_f32(const float* __restrict__ part, int nslices, int64_t elems, const int* __restrict__ map,
-                                                         float* __restrict__ grads, int K, int N, int Npad, int CO) {
-  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= elems) return;
-  int k = map[i];
-  if (k <= 0) return;
-  const int row = (int)(i / Npad), col = (int)(i - (int64_t)row * Npad);
+                                                         float* __restrict__ grads, int K, int N, int Npad, int CO, int groups) {
+  // (256 / groups) consecutive elements x `groups` slab groups per block; group g adds slabs g, g+groups, ...
+  // (four independent chains so the loads overlap); the groups are then added in order.
+  __shared__ float red[256];
+  const int epb = 256 / groups, e = threadIdx.x % epb, g = threadIdx.x / epb;
+  const int64_t i = (int64_t)blockIdx.x * epb + e;
+  int k = 0;
   float s = 0.f;
-  if (row == K) {
-    if (col >= CO) return;
-    for (int c = col; c < N; c += CO)
-      for (int z = 0; z < nslices; ++z) s += part[(int64_t)z * elems + (int64_t)row * Npad + c];
-  } else {
-    for (int z = 0; z < nslices; ++z) s += part[(int64_t)z * elems + i];
+  if (i < elems) {
+    k = map[i];
+    const int row = (int)(i / Npad), col = (int)(i - (int64_t)row * Npad);
+    if (k > 0) {
+      if (row == K) {
+        if (col >= CO) k = 0;
+        else
+          for (int z = g; z < nslices; z += groups)
+            for (int c = col; c < N; c += CO) s += part[(int64_t)z * elems + (int64_t)row * Npad + c];
+      } else {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int z = g;
+        for (; z + 3 * groups < nslices; z += 4 * groups) {
+          s0 += part[(int64_t)z * elems + i];
+          s1 += part[(int64_t)(z + groups) * elems + i];
+          s2 += part[(int64_t)(z + 2 * groups) * elems + i];
+          s3 += part[(int64_t)(z + 3 * groups) * elems + i];
+        }
+        for (; z < nslices; z += groups) s0 += part[(int64_t)z * elems + i];
+        s = (s0 + s1) + (s2 + s3);
+      }
+    }
   }
-  grads[k - 1] += s;
+  red[threadIdx.x] = s;
+  __syncthreads();
+  if (g == 0 && k > 0) {
+    float tot = red[e];
+    for (int q = 1; q < groups; ++q) tot += red[q * epb + e];
+    grads[k - 1] += tot;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -187,7 +413,6 @@ struct TrainOp {
   // wgrad
   std::vector<int> gmap;  // (K+1) x Npad -> flat param index + 1 (0: padding)
   int* d_gmap = nullptr;
-  int nslices = 1, rows_per_slice = 0;
 };
 
 struct DgradOp {
@@ -219,6 +444,7 @@ struct Trainer {
   std::vector<float*> Z, Y;       // per compute layer (Y aliases Z for linear layers)
   float* dbuf[2] = {nullptr, nullptr};
   float* d_part = nullptr; size_t part_elems = 0;
+  float* d_splitk = nullptr; size_t splitk_floats = 0;
   double* d_loss_partial = nullptr;
   ~Trainer();
 };
@@ -226,7 +452,7 @@ struct Trainer {
 Trainer::~Trainer() {
   (void)hipSetDevice(device);
   for (void* p : {(void*)d_pack, (void*)d_pack_map, (void*)d_dpack, (void*)d_dpack_map, (void*)d_zero_bias, (void*)dbuf[0], (void*)dbuf[1],
-                  (void*)d_part, (void*)d_loss_partial})
+                  (void*)d_part, (void*)d_loss_partial, (void*)d_splitk})
     if (p) (void)hipFree(p);
   for (size_t i = 0; i < Z.size(); ++i) {
     if (Y[i] && Y[i] != Z[i]) (void)hipFree(Y[i]);
@@ -355,9 +581,12 @@ static int trainer_build(Trainer& t, const Model& model, int max_batch) {
     for (int n = 0; n < d.N; ++n) to.gmap[(size_t)d.K * d.Npad + n] = (int)ipack[op.b_off + n];
     HIPCHECK(hipMalloc(&to.d_gmap, to.gmap.size() * sizeof(int)));
     HIPCHECK(hipMemcpy(to.d_gmap, to.gmap.data(), to.gmap.size() * sizeof(int), hipMemcpyHostToDevice));
-    const int64_t Mmax = (int64_t)max_batch * d.MH * d.MW;
-    to.nslices = (int)std::max<int64_t>(1, std::min<int64_t>(512, Mmax / 2048));
-    part_need = std::max(part_need, (size_t)to.nslices * to.gmap.size());
+    for (int b = 1; b <= max_batch; ++b) {  // the slab count is not monotonic in the batch
+      GemmDesc db = d;
+      db.M = b * d.MH * d.MW;
+      WgradPlan wp = wgrad_plan(db);
+      part_need = std::max(part_need, (size_t)wp.nslices * to.gmap.size());
+    }
     t.ops.push_back(std::move(to));
   }
   t.part_elems = part_need;
@@ -387,6 +616,13 @@ static int trainer_build(Trainer& t, const Model& model, int max_batch) {
   }
   for (auto*& b : t.dbuf) HIPCHECK(hipMalloc(&b, (size_t)max_batch * maxe * sizeof(float)));
   HIPCHECK(hipMalloc(&t.d_loss_partial, 1024 * sizeof(double)));
+  size_t sk = 0;
+  for (int b = 1; b <= max_batch; ++b) {
+    for (const TrainOp& op : t.ops) { GemmDesc d = op.fwd; d.M = b * d.MH * d.MW; sk = std::max(sk, gemm_splitk_ws_floats(d)); }
+    for (const DgradOp& op : t.dops) { GemmDesc d = op.d; d.M = b * d.MH * d.MW; sk = std::max(sk, gemm_splitk_ws_floats(d)); }
+  }
+  t.splitk_floats = sk;
+  if (sk) HIPCHECK(hipMalloc(&t.d_splitk, sk * sizeof(float)));
   return SRCFD_OK;
 }
 
@@ -403,7 +639,7 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
     GemmDesc d = op.fwd;
     d.M = n * d.MH * d.MW;
     const float* X = op.layer == 0 ? x : t.Y[op.layer - 1];
-    HIPCHECK(launch_gemm_mfma(d, X, t.d_pack + op.w_off, t.d_pack + op.b_off, t.Z[op.layer], s));
+    HIPCHECK(launch_gemm_mfma(d, X, t.d_pack + op.w_off, t.d_pack + op.b_off, t.Z[op.layer], s, t.d_splitk, t.splitk_floats));
     const bool last_of_layer = (&op == &t.ops.back()) || ((&op + 1)->layer != op.layer);
     if (last_of_layer && t.layers[op.layer].swish) {
       int64_t e = (int64_t)n * t.layers[op.layer].out_elems;
@@ -415,7 +651,7 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
   int64_t oe = (int64_t)n * t.layers[L - 1].out_elems;
   int nb = (int)std::min<int64_t>(1024, (oe + 255) / 256);
   hipLaunchKernelGGL(mse_grad_f32, dim3(nb), dim3(256), 0, s, t.Y[L - 1], y, t.dbuf[0], oe, loss_scale, t.d_loss_partial);
-  if (sse_dev) hipLaunchKernelGGL(sum_partials_f64, dim3(1), dim3(64), 0, s, t.d_loss_partial, nb, sse_dev);
+  if (sse_dev) hipLaunchKernelGGL(sum_partials_f64, dim3(1), dim3(256), 0, s, t.d_loss_partial, nb, sse_dev);
   // 4. backward
   int cur = 0;
   for (int li = L - 1; li >= 0; --li) {
@@ -427,20 +663,19 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
       if (op.layer != li) continue;
       GemmDesc d = op.fwd;
       d.M = n * d.MH * d.MW;
-      const int ktiles = (d.K + 1 + 31) / 32, ntiles = (d.N + 31) / 32;
-      int nslices = (int)std::max<int64_t>(1, std::min<int64_t>(op.nslices, ((int64_t)d.M + 2047) / 2048));
-      int rps = (d.M + nslices - 1) / nslices;
-      rps = (rps + 1) & ~1;
-      nslices = (d.M + rps - 1) / rps;
+      const WgradPlan wp = wgrad_plan(d);
       const int64_t elems = (int64_t)(d.K + 1) * d.Npad;
-      hipLaunchKernelGGL(wgrad_f32, dim3(ktiles * ntiles, (nslices + 3) / 4), dim3(256), 0, s, d, X, dZ, t.d_part, rps, nslices, ktiles);
-      hipLaunchKernelGGL(wgrad_finish_f32, grid(elems), dim3(256), 0, s, t.d_part, nslices, elems, op.d_gmap, grads, d.K, d.N, d.Npad, d.CO);
+      if ((size_t)wp.nslices * elems > t.part_elems) { set_error("training: gradient slab buffer too small"); return SRCFD_EINVAL; }
+      launch_wgrad(d, wp, X, dZ, t.d_part, s);
+      const int groups = wp.nslices >= 64 ? 8 : (wp.nslices >= 8 ? 4 : 1), epb = 256 / groups;
+      hipLaunchKernelGGL(wgrad_finish_f32, dim3((unsigned)((elems + epb - 1) / epb)), dim3(256), 0, s, t.d_part, wp.nslices, elems, op.d_gmap, grads,
+                         d.K, d.N, d.Npad, d.CO, groups);
     }
     if (li > 0) {
       const DgradOp& dg = t.dops[li - 1];
       GemmDesc d = dg.d;
       d.M = n * d.MH * d.MW;
-      HIPCHECK(launch_gemm_mfma(d, dZ, t.d_dpack + dg.w_off, t.d_zero_bias, t.dbuf[cur ^ 1], s));
+      HIPCHECK(launch_gemm_mfma(d, dZ, t.d_dpack + dg.w_off, t.d_zero_bias, t.dbuf[cur ^ 1], s, t.d_splitk, t.splitk_floats));
       cur ^= 1;
     }
   }

@@ -98,6 +98,15 @@ def test_gradients_match_autograd_oracle(srcfd, oracle, enc_weights, dec_weights
     t.forward_backward(xd, yd)
     torch.cuda.synchronize()
     assert torch.equal(g1, t.grads)
+    # data parallelism by construction: per-rank gradients of the global mean add up to the full-batch gradient
+    t.grads.zero_()
+    t.forward_backward(xd[:2].contiguous(), yd[:2].contiguous(), global_batch=n)   # "rank 0"
+    ga = t.grads.clone()
+    t.grads.zero_()
+    t.forward_backward(xd[2:].contiguous(), yd[2:].contiguous(), global_batch=n)   # "rank 1"
+    torch.cuda.synchronize()
+    summed = (ga + t.grads).cpu().numpy().astype(np.float64)
+    assert np.linalg.norm(summed - g) <= 1e-5 * np.linalg.norm(g)
 
 
 @pytest.mark.gpu
