@@ -291,6 +291,58 @@ __global__ void __launch_bounds__(256) conv_n1_f32(GemmDesc d, const float* __re
   Y[out_offset(d, img, my, mx, 0)] = act_apply_precise(acc, d.act);
 }
 
+// Same layer, four horizontally adjacent outputs per thread: a 3-wide tap window over 4 pixels touches
+// 6 input pixels per kernel row instead of 12, halving the L1 traffic that bounds conv_n1_f32.
+// Needs unit stride, a 3x3 kernel, 8 input channels and rows that are a multiple of 4 wide.
+__global__ void __launch_bounds__(256) conv_n1x4_f32(GemmDesc d, const float* __restrict__ X, const float* __restrict__ B,
+                                                      const float* __restrict__ bias, float* __restrict__ Y) {
+  __shared__ float w[512];
+  for (int i = threadIdx.x; i < d.K; i += 256) w[i] = B[(int64_t)i * d.Npad];
+  __syncthreads();
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx * 4 >= d.M) return;
+  int img, my, mx;
+  row_decode(d, (int)(idx * 4), img, my, mx);
+  const float b0 = bias[0];
+  float acc[4] = {b0, b0, b0, b0};
+  // all 36 loads are issued before the first FMA: out-of-range taps read a clamped (valid) address and
+  // are zeroed afterwards, so there is no branch between the loads and they overlap in flight
+  float4 v[3][6][2];
+#pragma unroll
+  for (int ty = 0; ty < 3; ++ty) {
+    const int iy = my + ty * d.by + d.cy;
+    const bool yok = iy >= 0 && iy < d.IH;
+    const float* row = X + ((int64_t)img * d.IH + min(max(iy, 0), d.IH - 1)) * d.IW * 8;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int ix = mx + d.cx + j;
+      const bool ok = yok && ix >= 0 && ix < d.IW;
+      const float* px = row + (int64_t)min(max(ix, 0), d.IW - 1) * 8;
+      float4 a = *reinterpret_cast<const float4*>(px), c = *reinterpret_cast<const float4*>(px + 4);
+      v[ty][j][0] = ok ? a : make_float4(0.f, 0.f, 0.f, 0.f);
+      v[ty][j][1] = ok ? c : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+#pragma unroll
+  for (int ty = 0; ty < 3; ++ty) {
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx) {
+      const float* wp = w + (ty * 3 + tx) * 8;
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const float4 a = v[ty][p + tx][0], c = v[ty][p + tx][1];
+        float t = acc[p];
+        t = fmaf(a.x, wp[0], t); t = fmaf(a.y, wp[1], t); t = fmaf(a.z, wp[2], t); t = fmaf(a.w, wp[3], t);
+        t = fmaf(c.x, wp[4], t); t = fmaf(c.y, wp[5], t); t = fmaf(c.z, wp[6], t); t = fmaf(c.w, wp[7], t);
+        acc[p] = t;
+      }
+    }
+  }
+  *reinterpret_cast<float4*>(Y + out_offset(d, img, my, mx, 0)) =
+      make_float4(act_apply_precise(acc[0], d.act), act_apply_precise(acc[1], d.act), act_apply_precise(acc[2], d.act),
+                  act_apply_precise(acc[3], d.act));
+}
+
 // single-input-channel conv with <= 8 output channels (the data gradient of `output_image_400`:
 // a 3x3 1->8 flipped-tap conv over 400x400): one thread per pixel, 8 accumulators, two 16-byte stores.
 __global__ void __launch_bounds__(256) conv_ci1_f32(GemmDesc d, const float* __restrict__ X, const float* __restrict__ B,
@@ -306,12 +358,13 @@ __global__ void __launch_bounds__(256) conv_ci1_f32(GemmDesc d, const float* __r
 #pragma unroll
   for (int c = 0; c < 8; ++c) acc[c] = c < d.N ? bias[c] : 0.f;
   for (int ty = 0; ty < d.TY; ++ty) {
-    int iy = my * d.ay + ty * d.by + d.cy;
-    if (iy < 0 || iy >= d.IH) continue;
+    const int iy = my * d.ay + ty * d.by + d.cy;
+    const bool yok = iy >= 0 && iy < d.IH;
+    const float* row = X + ((int64_t)img * d.IH + min(max(iy, 0), d.IH - 1)) * d.IW;
     for (int tx = 0; tx < d.TX; ++tx) {
-      int ix = mx * d.ax + tx * d.bx + d.cx;
-      if (ix < 0 || ix >= d.IW) continue;
-      float v = X[((int64_t)img * d.IH + iy) * d.IW + ix];
+      const int ix = mx * d.ax + tx * d.bx + d.cx;
+      float v = row[min(max(ix, 0), d.IW - 1)];       // clamped address, zeroed below: no branch around the load
+      v = (yok && ix >= 0 && ix < d.IW) ? v : 0.f;
       const float* wp = w + (ty * d.TX + tx) * 8;
 #pragma unroll
       for (int c = 0; c < 8; ++c) acc[c] = fmaf(v, wp[c], acc[c]);
@@ -410,6 +463,11 @@ size_t gemm_splitk_ws_floats(const GemmDesc& d) {
 hipError_t launch_gemm_mfma(const GemmDesc& d, const float* X, const float* B, const float* bias, float* Y, hipStream_t s, float* ws,
                             size_t ws_floats) {
   if (d.M == 0 || d.N == 0) return hipSuccess;
+  if (d.N == 1 && d.nphx == 1 && d.TX == 3 && d.TY == 3 && d.CI == 8 && d.ax == 1 && d.bx == 1 && d.ay == 1 && d.os == 1 && d.ox0 == 0 && d.OC == 1 &&
+      d.MW % 4 == 0 && d.OW % 4 == 0 && d.K <= 512) {
+    hipLaunchKernelGGL(conv_n1x4_f32, dim3((unsigned)((d.M / 4 + 255) / 256)), dim3(256), 0, s, d, X, B, bias, Y);
+    return hipGetLastError();
+  }
   if (d.N == 1 && d.K <= 512 && d.nphx == 1) {
     hipLaunchKernelGGL(conv_n1_f32, dim3((unsigned)((d.M + 255) / 256)), dim3(256), 0, s, d, X, B, bias, Y);
     return hipGetLastError();

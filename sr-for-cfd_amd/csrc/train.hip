@@ -299,13 +299,14 @@ __global__ void __launch_bounds__(256) wgrad_n1_k72_f32(GemmDesc d, const float*
 #pragma unroll
       for (int tx = 0; tx < 3; ++tx) {
         int ix = mx * d.ax + tx * d.bx + d.cx;
-        if (iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW) {
-          const float4* xp = reinterpret_cast<const float4*>(X + (((int64_t)img * d.IH + iy) * d.IW + ix) * 8);
-          float4 a = xp[0], b = xp[1];
-          float* ap = acc + (ty * 3 + tx) * 8;
-          ap[0] = fmaf(a.x, g, ap[0]); ap[1] = fmaf(a.y, g, ap[1]); ap[2] = fmaf(a.z, g, ap[2]); ap[3] = fmaf(a.w, g, ap[3]);
-          ap[4] = fmaf(b.x, g, ap[4]); ap[5] = fmaf(b.y, g, ap[5]); ap[6] = fmaf(b.z, g, ap[6]); ap[7] = fmaf(b.w, g, ap[7]);
-        }
+        const bool ok = iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW;
+        const float4* xp = reinterpret_cast<const float4*>(
+            X + (((int64_t)img * d.IH + min(max(iy, 0), d.IH - 1)) * d.IW + min(max(ix, 0), d.IW - 1)) * 8);
+        const float4 a = xp[0], b = xp[1];   // clamped address; the gradient factor is zeroed instead of branching
+        const float gg = ok ? g : 0.f;
+        float* ap = acc + (ty * 3 + tx) * 8;
+        ap[0] = fmaf(a.x, gg, ap[0]); ap[1] = fmaf(a.y, gg, ap[1]); ap[2] = fmaf(a.z, gg, ap[2]); ap[3] = fmaf(a.w, gg, ap[3]);
+        ap[4] = fmaf(b.x, gg, ap[4]); ap[5] = fmaf(b.y, gg, ap[5]); ap[6] = fmaf(b.z, gg, ap[6]); ap[7] = fmaf(b.w, gg, ap[7]);
       }
     }
   }
