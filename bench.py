@@ -53,6 +53,20 @@ def build_inputs(fields, seed, stats_lr, stats_hr):
     return x, ain, aout
 
 
+def measured_traffic(args):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (bench.py cannot
+    run the profiler on itself); None unless the profile was taken on this exact configuration."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic_tail.json")) as f:
+            t = json.load(f)
+    except OSError:
+        return None, None
+    c = t.get("config", {})
+    if (c.get("fields"), c.get("precision"), c.get("out_dtype")) != (args.fields, args.precision, args.out_dtype):
+        return None, None
+    return t["hbm_bytes_per_launch"], t["source"]
+
+
 def tail_flops(n):
     macs = 3 * 20_480_000 + 11_520_000  # ConvT#2..#4 + output conv (SURVEY.md 8a rows a15-a18)
     return 2.0 * macs * n
@@ -178,8 +192,11 @@ def main():
             fl, peak = None, PEAK_FP32_TFLOPS
         if fl is not None:
             ach = fl / (kernels[dom] * 1e-3) / 1e12
+            traffic, traffic_src = measured_traffic(args)
             roofline = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                        "frac": round(ach / peak, 4), "traffic": None, "avg_launch_ms": kernels[dom],
+                        "frac": round(ach / peak, 4), "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC)",
+                        "traffic_source": traffic_src, "algorithmic_bytes_per_launch": n * 160000 * (2 + (4 if args.out_dtype == "f32" else 2)),
+                        "avg_launch_ms": kernels[dom],
                         "algorithmic_flops_per_launch": fl,
                         "note": "swish = 2 quarter-rate transcendentals per activation: the VALU ceiling of this network is ~0.45 of the MFMA peak (DESIGN.md 4.2)"}
         else:
