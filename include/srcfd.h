@@ -70,6 +70,7 @@ typedef struct srcfd_model srcfd_model;
 typedef struct srcfd_h5 srcfd_h5;
 typedef struct srcfd_h5w srcfd_h5w;
 typedef struct srcfd_trainer srcfd_trainer;
+typedef struct srcfd_resampler srcfd_resampler;
 
 const char* srcfd_last_error(void);
 const char* srcfd_version(void);
@@ -182,6 +183,23 @@ int srcfd_h5w_save(srcfd_h5w* w, const char* path);
 /* Saves the handle's weights as legacy Keras-H5 sub-model files
  * (sr-ae-conv.ipynb:c584-585); split_at = index of the first decoder layer. */
 int srcfd_model_save_h5(const srcfd_model* m, const char* encoder_h5, const char* decoder_h5);
+
+/* ---- device-side resampling of the SR output (BFS aspect-ratio correction) -------------------
+ * Replaces `reshape_square_to_rectangular` (bfs_ml_accelerated.py:104-145): per component
+ * RectBivariateSpline(y_sq, x_sq, field, kx=3, ky=3)(y_rect, x_rect) is linear in `field` and
+ * separable, i.e. out = Ry * field * Rx^T with the 1-D interpolating-spline matrices
+ * Ry [out_h][in_h], Rx [out_w][in_w] (row-major float64, host; built once by the caller, see
+ * sr-for-cfd_amd/resample.py).  The handle keeps them on `device`. */
+int srcfd_resampler_create(int device, const double* Ry, const double* Rx, int in_h, int in_w, int out_h, int out_w,
+                           srcfd_resampler** out);
+void srcfd_resampler_destroy(srcfd_resampler* r);
+/* in_dev float32 (n,in_h,in_w) -> out_dev float64 (n,out_h,out_w), enqueued on hip_stream. */
+int srcfd_resample_device(srcfd_resampler* r, const float* in_dev, int n, double* out_dev, void* hip_stream);
+/* srcfd_predict followed by the resampling, without the float32 result leaving the device:
+ * `predict` + inverse standardise + NaN guard (bfs_ml_accelerated.py:1109-1127) + resample back
+ * (:1130-1135).  y is float64 host (n,out_h,out_w), like scipy returns it. */
+int srcfd_predict_resampled(srcfd_model* m, srcfd_resampler* r, const float* x, int n, const float* in_affine,
+                            const float* out_affine, double* y, int flags, int64_t* n_nonfinite);
 
 /* ---- training -----------------------------------------------------------
  * One optimisation step of SuperResolutionAE, split so that a data-parallel driver can put its

@@ -89,6 +89,10 @@ _protos = {
     "srcfd_model_get_profile": (C.c_int, [_p, C.c_char_p, _sz, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]),
     "srcfd_model_debug_activation": (C.c_int, [_p, C.c_int, _p, _sz]),
     "srcfd_model_save_h5": (C.c_int, [_p, C.c_char_p, C.c_char_p]),
+    "srcfd_resampler_create": (C.c_int, [C.c_int, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_p)]),
+    "srcfd_resampler_destroy": (None, [_p]),
+    "srcfd_resample_device": (C.c_int, [_p, _p, C.c_int, _p, _p]),
+    "srcfd_predict_resampled": (C.c_int, [_p, _p, _p, C.c_int, _p, _p, _p, C.c_int, C.POINTER(C.c_int64)]),
     "srcfd_trainer_create": (C.c_int, [_p, C.c_int, C.POINTER(_p)]),
     "srcfd_trainer_destroy": (None, [_p]),
     "srcfd_trainer_num_params": (C.c_int64, [_p]),

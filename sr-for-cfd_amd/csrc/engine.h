@@ -83,7 +83,9 @@ struct Model {
                       unsigned long long* nonfinite, hipStream_t s);
   int predict_device(const void* x_dev, int n, const float* aff_in, const float* aff_out, void* y_dev, int out_dtype, int flags,
                      unsigned long long* nonfinite, hipStream_t s);
-  int predict_host(const float* x, int n, const float* aff_in, const float* aff_out, float* y, int flags, int64_t* n_nonfinite);
+  // sink (optional): consumes each chunk's device result [first, first+count) on the default stream instead of the copy into y
+  int predict_host(const float* x, int n, const float* aff_in, const float* aff_out, float* y, int flags, int64_t* n_nonfinite,
+                   const std::function<int(const float* y_dev, int first, int count)>& sink = nullptr);
 };
 
 // bf16 / f16 fused path for the encoder_10 + decoder_400 graph.

@@ -304,9 +304,10 @@ int Model::predict_device(const void* x_dev, int n, const float* aff_in, const f
   return SRCFD_OK;
 }
 
-int Model::predict_host(const float* x, int n, const float* aff_in, const float* aff_out, float* y, int flags, int64_t* n_nonfinite) {
+int Model::predict_host(const float* x, int n, const float* aff_in, const float* aff_out, float* y, int flags, int64_t* n_nonfinite,
+                        const std::function<int(const float*, int, int)>& sink) {
   if (device < 0) { set_error("host-only handle: no device was requested at create"); return SRCFD_ENODEV; }
-  if (n < 0 || (n > 0 && (!x || !y))) { set_error("bad arguments"); return SRCFD_EINVAL; }
+  if (n < 0 || (n > 0 && (!x || (!y && !sink)))) { set_error("bad arguments"); return SRCFD_EINVAL; }
   if (n_nonfinite) *n_nonfinite = 0;
   if (n == 0) return SRCFD_OK;
   HIPCHECK(hipSetDevice(device));
@@ -333,7 +334,8 @@ int Model::predict_host(const float* x, int n, const float* aff_in, const float*
     if (aff_out) { aout = d_aff + 2 * (size_t)stage_chunk; HIPCHECK(hipMemcpyAsync(aout, aff_out + 2 * (size_t)i, (size_t)c * 2 * sizeof(float), hipMemcpyHostToDevice, nullptr)); }
     int rc = predict_device(d_x_stage, c, ain, aout, d_y_stage, SRCFD_F32, flags, d_nonfinite, nullptr);
     if (rc) return rc;
-    HIPCHECK(hipMemcpyAsync(y + (size_t)i * out_elems, d_y_stage, c * out_elems * sizeof(float), hipMemcpyDeviceToHost, nullptr));
+    if (sink) { rc = sink(d_y_stage, i, c); if (rc) return rc; }
+    else HIPCHECK(hipMemcpyAsync(y + (size_t)i * out_elems, d_y_stage, c * out_elems * sizeof(float), hipMemcpyDeviceToHost, nullptr));
     HIPCHECK(hipStreamSynchronize(nullptr));
   }
   if (n_nonfinite) {

@@ -217,6 +217,31 @@ class SRModel:
             return y, int(bad.value)
         return y
 
+    def predict_resampled(self, x: np.ndarray, resampler, in_affine=None, out_affine=None, nan_guard: bool = False,
+                          return_nonfinite: bool = False):
+        """`predict` + resampling of every (H,W) output by `resampler` (float64 result, like scipy's), the
+        float32 network output never leaving the device (bfs_ml_accelerated.py:1109-1135)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        n = x.shape[0]
+        if tuple(x.shape[1:]) != self.input_shape:
+            raise ValueError(f"expected input (N,{self.input_shape}), got {x.shape}")
+
+        def aff(a):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            if a.shape != (n, 2):
+                raise ValueError("affine must have shape (N, 2)")
+            return a
+        ai, ao = aff(in_affine), aff(out_affine)
+        y = np.empty((n, resampler.out_h, resampler.out_w), np.float64)
+        bad = C.c_int64(0)
+        L.check(L.lib.srcfd_predict_resampled(self._h, resampler._h, x.ctypes.data_as(C.c_void_p), n,
+                                              ai.ctypes.data_as(C.c_void_p) if ai is not None else None,
+                                              ao.ctypes.data_as(C.c_void_p) if ao is not None else None,
+                                              y.ctypes.data_as(C.c_void_p), L.FLAG_NAN_GUARD if nan_guard else 0, C.byref(bad)))
+        return (y, int(bad.value)) if return_nonfinite else y
+
     def predict_device(self, x, y, in_affine=None, out_affine=None, nan_guard=False, nonfinite=None, stream=None):
         """Device-resident forward on torch CUDA tensors (plumbing only):
         x float32 (n,h,w,c); y float32/bfloat16/float16 (n,oh,ow,oc); affines

@@ -10,8 +10,9 @@ Order of operations is the reference's: float32 cast, [BFS: spline resample to a
 square], stats lookup, [BFS: adaptive blend], standardise, predict, de-standardise
 with the *training* HR stats, NaN/Inf zero-fill, [BFS: resample back].  Standardise,
 the network, de-standardise and the guard run as one device call for the three
-components; the 10x10 statistics and the splines stay on the host (scipy, as in
-the reference).
+components.  The BFS resample back to the rectangle (a bicubic spline fit of a 400x400
+field per component in the reference) runs on the device as two float64 matrix products
+(resample.py); the 10x10 statistics and the 10x10 pre-resampling stay on the host.
 """
 from __future__ import annotations
 
@@ -98,15 +99,20 @@ def ml_super_resolution(coarse_fields: Dict[str, np.ndarray], lr_dim: int, hr_di
         ain[i] = (mean_lr, std_lr)
         aout[i] = stats_hr[c]
 
-    y, bad = model.predict(x, in_affine=ain, out_affine=aout, nan_guard=True, return_nonfinite=True)
+    resample_back = use_aspect_ratio_correction and lx != ly
+    if resample_back:
+        from . import resample as rs
+        back = rs.square_to_rect_resampler(hr_dim, hr_dim, hr_dim, float(lx), float(ly), model.device)
+        y, bad = model.predict_resampled(x, back, in_affine=ain, out_affine=aout, nan_guard=True, return_nonfinite=True)
+        y = y[..., None]
+    else:
+        y, bad = model.predict(x, in_affine=ain, out_affine=aout, nan_guard=True, return_nonfinite=True)
     if bad:
         warnings.warn(f"super-resolved fields contained {bad} NaN/Inf values; replaced with zeros "
                       "(PyCFD_ML_accelerated.py:869-876)", RuntimeWarning)
     hr = {c: y[i, :, :, 0] for i, c in enumerate(COMPONENTS)}
     for c in COMPONENTS:
         say(f"  {c.upper()}: {fields[c].shape} -> {hr[c].shape}, range [{hr[c].min():.6f}, {hr[c].max():.6f}]")
-    if use_aspect_ratio_correction and lx != ly:
-        hr = reshape_square_to_rectangular(hr, hr_dim, hr_dim, lx, ly)
     return hr
 
 

@@ -1,0 +1,62 @@
+"""BFS aspect-ratio resampling (bfs_ml_accelerated.py:59-145) as matrix products: the 1-D spline
+matrices against scipy's RectBivariateSpline (what the reference calls), and the device kernels."""
+import importlib
+
+import numpy as np
+import pytest
+
+from conftest import require_gpu
+
+
+def _scipy_resample(field, src_y, src_x, dst_y, dst_x):
+    from scipy import interpolate
+    return interpolate.RectBivariateSpline(src_y, src_x, field, kx=3, ky=3)(dst_y, dst_x)
+
+
+@pytest.mark.parametrize("lx,ly", [(10.0, 3.0), (2.0, 5.0), (1.0, 1.0)])
+def test_matrices_reproduce_rect_bivariate_spline(srcfd, lx, ly):
+    rs = importlib.import_module("sr-for-cfd_amd.resample")
+    rng = np.random.default_rng(3)
+    L = max(lx, ly)
+    # square -> rectangle at the fine size (post-processing), including FITPACK's clamping outside the data interval
+    n = 400
+    f = rng.standard_normal((n, n))
+    Ry, Rx = rs.square_to_rect_matrices(n, n, n, lx, ly)
+    ref = _scipy_resample(f, np.linspace(0, L, n), np.linspace(0, L, n), np.linspace(0, ly, n), np.linspace(0, lx, n))
+    assert np.abs(Ry @ f @ Rx.T - ref).max() <= 1e-12 * np.abs(ref).max()
+    # rectangle -> square at the coarse size (pre-processing): evaluation points beyond the data are clamped
+    n = 10
+    f = rng.standard_normal((n, n))
+    Ry, Rx = rs.rect_to_square_matrices(n, n, lx, ly)
+    ref = _scipy_resample(f, np.linspace(0, ly, n), np.linspace(0, lx, n), np.linspace(0, L, n), np.linspace(0, L, n))
+    assert np.abs(Ry @ f @ Rx.T - ref).max() <= 1e-12 * np.abs(ref).max()
+
+
+def test_resampler_needs_a_device(srcfd):
+    rs = importlib.import_module("sr-for-cfd_amd.resample")
+    if srcfd.device_count() > 0:
+        pytest.skip("box has a GPU")
+    with pytest.raises(srcfd.NoDeviceError):
+        rs.Resampler(np.eye(4), np.eye(4), device=0)
+
+
+@pytest.mark.gpu
+def test_device_resampling_matches_scipy(srcfd):
+    require_gpu(srcfd)
+    import torch
+    rs = importlib.import_module("sr-for-cfd_amd.resample")
+    rng = np.random.default_rng(4)
+    n, lx, ly = 400, 10.0, 3.0
+    f = rng.standard_normal((3, n, n)).astype(np.float32)
+    r = rs.square_to_rect_resampler(n, n, n, lx, ly, 0)
+    out = r.apply_device(torch.from_numpy(f).cuda()).cpu().numpy()
+    assert out.dtype == np.float64 and out.shape == (3, n, n)
+    for c in range(3):
+        ref = _scipy_resample(f[c].astype(np.float64), np.linspace(0, 10, n), np.linspace(0, 10, n), np.linspace(0, ly, n), np.linspace(0, lx, n))
+        assert np.abs(out[c] - ref).max() <= 1e-12 * np.abs(ref).max()
+    # ragged sizes exercise the tile edges: 37x53 -> 41x29 with arbitrary matrices
+    Ry, Rx = rng.standard_normal((41, 37)), rng.standard_normal((29, 53))
+    g = rng.standard_normal((2, 37, 53)).astype(np.float32)
+    got = rs.Resampler(Ry, Rx, 0).apply_device(torch.from_numpy(g).cuda()).cpu().numpy()
+    want = np.einsum("oh,zhw,pw->zop", Ry, g.astype(np.float64), Rx)
+    assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""BASELINE configs 1 and 3: latency of ONE `ml_super_resolution` call as the solvers make it
+(host numpy in, host numpy out, 3 components of one 10x10 field -> 400x400), end to end through the
+drop-in Python surface, next to the oracle's torch-CPU port of the same call on the host cores.
+
+    python tools/latency_bench.py [--calls 50]
+Prints one JSON line per variant."""
+import argparse
+import importlib
+import json
+import os
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+ENC = os.path.join(GOLDEN, "vanilla_encoder10_to_400_swish_trained_upto_700_multiBC.h5")
+STATS = os.path.join(GOLDEN, "standardization_stats_10to400_swish_trained_upto_700_multiBC.txt")
+
+
+def timeit(fn, calls, warm=3):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(calls):
+        t0 = time.perf_counter()
+        fn()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    ts = np.array(ts)
+    return {"median_ms": round(float(np.median(ts)), 4), "p90_ms": round(float(np.percentile(ts, 90)), 4), "min_ms": round(float(ts.min()), 4)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--calls", type=int, default=50)
+    args = ap.parse_args()
+    srcfd = importlib.import_module("sr-for-cfd_amd")
+    synth = importlib.import_module("sr-for-cfd_amd.synth")
+    pl = importlib.import_module("sr-for-cfd_amd.pipeline")
+    h5 = importlib.import_module("sr-for-cfd_amd.h5")
+    dec_w = synth.synthetic_decoder_weights(1)
+    tmp = tempfile.mkdtemp()
+    dec = os.path.join(tmp, "vanilla_decoder400_from_10_synthetic.h5")
+    srcfd.SRModel.from_weights(None, dec_w, device=-1).save_h5(None, dec)
+    ldc = h5.read_coarse_fields(os.path.join(GOLDEN, "coarse_ldc_Re1000_double_lid.h5"))
+    bfs = h5.read_coarse_fields(os.path.join(GOLDEN, "coarse_bfs_Re400.h5"))
+    for prec in ("fp32", "bf16"):
+        r = timeit(lambda: pl.ml_super_resolution(ldc, 10, 400, STATS, ENC, dec, precision=prec), args.calls)
+        print(json.dumps({"call": "ml_super_resolution (LDC, PyCFD_ML_accelerated.py:764)", "precision": prec, **r}))
+        r = timeit(lambda: pl.ml_super_resolution_bfs(bfs, 10, 400, STATS, ENC, dec, use_aspect_ratio_correction=True, lx=10.0, ly=3.0,
+                                                      precision=prec), args.calls)
+        print(json.dumps({"call": "ml_super_resolution (BFS: spline resample + adaptive blend, bfs_ml_accelerated.py:979)", "precision": prec, **r}))
+    # host-core stand-in for the reference's Keras call: the oracle's torch-CPU port, same pre/post
+    import torch
+    from oracle import sr_oracle as o
+    from oracle.sr_oracle_torch import TorchSR
+    enc_w = srcfd.SRModel.load_h5(ENC, None, device=-1).weights()
+    model = TorchSR(enc_w, dec_w, torch.float32)
+    stats = o.parse_stats(STATS)
+
+    def cpu_call():
+        out = {}
+        for c in "uvp":
+            x = np.asarray(ldc[c]).astype(np.float32)
+            x = (x - stats[f"mean10_{c}"]) / stats[f"std10_{c}"]
+            y = model.forward(x[None, :, :, None].astype(np.float32), batch_size=1)[0, :, :, 0]
+            out[c] = y * stats[f"std400_{c}"] + stats[f"mean400_{c}"]
+        return out
+    r = timeit(cpu_call, max(5, args.calls // 5), warm=2)
+    print(json.dumps({"call": "torch-CPU/oneDNN port of the same call (3 predicts of batch 1, like the reference)", "precision": "f32",
+                      "cores": int(torch.get_num_threads()), **r}))
+
+
+if __name__ == "__main__":
+    main()
