@@ -6,7 +6,8 @@
 
 A step = forward + backward + flat-gradient all-reduce (RCCL) + Adam on a per-GPU micro-batch of
 `--batch` synthetic (10x10x1 -> 400x400x1) pairs (the notebook trains with batch 8,
-sr-ae-conv.ipynb:c558).  Weak scaling: global batch = batch x N.  Prints one JSON line on rank 0."""
+sr-ae-conv.ipynb:c558).  Weak scaling: global batch = batch x N; `--global-batch 256` = strong scaling
+(SURVEY.md 8d config 4).  Prints one JSON line on rank 0."""
 import argparse
 import importlib
 import json
@@ -25,6 +26,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--global-batch", type=int, default=0, help="strong scaling: split this global batch over the ranks")
     ap.add_argument("--profile", action="store_true", help="per-phase HIP-event timing on rank 0")
     args = ap.parse_args()
     import torch
@@ -40,16 +42,18 @@ def main():
     srcfd = importlib.import_module("sr-for-cfd_amd")
     synth = importlib.import_module("sr-for-cfd_amd.synth")
     tr = importlib.import_module("sr-for-cfd_amd.train")
-    enc = synth.synthetic_encoder_weights(2) if hasattr(synth, "synthetic_encoder_weights") else None
-    if enc is None:
-        enc = srcfd.SRModel.load_h5(os.path.join(ROOT, "tests", "golden", "vanilla_encoder10_to_400_swish_trained_upto_700_multiBC.h5"),
-                                    None, device=-1).weights()
-    model = srcfd.SRModel.from_weights(enc, synth.synthetic_decoder_weights(1), device=local)
-    t = tr.Trainer(model, max_batch=args.batch)
-    rng = np.random.default_rng(100 + rank)
-    x = torch.from_numpy(rng.standard_normal((args.batch, 10, 10, 1)).astype(np.float32)).to(dev)
-    y = torch.from_numpy(rng.standard_normal((args.batch, 400, 400, 1)).astype(np.float32)).to(dev)
-    gb = args.batch * world
+    ds = importlib.import_module("sr-for-cfd_amd.datasets")
+    enc, dec = synth.keras_default_init(0)                     # identical replicas: same seed on every rank
+    model = srcfd.SRModel.from_weights(enc, dec, device=local)
+    batch = args.batch if not args.global_batch else args.global_batch // world   # strong scaling: fixed global batch
+    t = tr.Trainer(model, max_batch=batch)
+    # the notebook's own dummy recipe (sr-ae-conv.ipynb:c72-91): x_hr ~ N(0,1), x_lr = avg_pool(x_hr, 40); seed 0 (+rank)
+    rng = np.random.default_rng(rank)
+    y_h = rng.standard_normal((batch, 400, 400, 1)).astype(np.float32)
+    x = torch.from_numpy(ds.avg_pool(y_h, 40)).to(dev)
+    y = torch.from_numpy(y_h).to(dev)
+    args.batch = batch
+    gb = batch * world
     losses = []
     for _ in range(args.warmup):
         t.step(x, y, gb)
@@ -89,7 +93,7 @@ def main():
         flops = 3 * 2 * 140_024_128 * gb  # fwd + dgrad + wgrad
         print(json.dumps({"metric": "conv-AE training samples/sec (10x10->400x400, f32, Adam)", "value": round(gb / (ms * 1e-3), 2),
                           "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
-                          "scaling": "weak", "dtype": "f32", "data": "synthetic", "micro_batch": args.batch, "global_batch": gb,
+                          "scaling": "strong" if args.global_batch else "weak", "dtype": "f32", "data": "synthetic", "micro_batch": args.batch, "global_batch": gb,
                           "params": t.n_params, "tflops_model": round(flops / (ms * 1e-3) / 1e12, 2), "phases": phases}))
     if world > 1:
         dist.destroy_process_group()
