@@ -430,9 +430,24 @@ int srcfd_model_create(const srcfd_layer* layers, int n_layers, const int in_sha
     }
     m->desc.layers.push_back(std::move(L));
   }
-  srcfd::SubModel sub;
-  sub.name = "model"; sub.input_name = "model_input"; sub.first = 0; sub.count = n_layers;
-  m->desc.subs.push_back(sub);
+  // A graph with a `latent_vector` layer in the middle is the encoder/decoder pair of SuperResolutionAE
+  // (sr-ae-conv.ipynb:c162-169, c277-287): keep the two halves as separate sub-models so that save_h5 writes the
+  // `vanilla_encoder...h5` / `vanilla_decoder...h5` pair the solvers load (PyCFD_ML_accelerated.py:831-832).
+  int cut = -1;
+  for (int i = 0; i + 1 < n_layers; ++i)
+    if (m->desc.layers[i].name == "latent_vector") cut = i + 1;
+  if (cut > 0) {
+    try { m->desc.infer_shapes(); } catch (const std::exception& e) { set_error(e.what()); return SRCFD_EINVAL; }
+    srcfd::SubModel enc, dec;
+    enc.name = "encoder_" + std::to_string(in_shape[0]); enc.input_name = enc.name + "_input"; enc.first = 0; enc.count = cut;
+    dec.name = "decoder_" + std::to_string(m->desc.out_shape()[0]); dec.input_name = dec.name + "_input"; dec.first = cut; dec.count = n_layers - cut;
+    m->desc.subs.push_back(enc);
+    m->desc.subs.push_back(dec);
+  } else {
+    srcfd::SubModel sub;
+    sub.name = "model"; sub.input_name = "model_input"; sub.first = 0; sub.count = n_layers;
+    m->desc.subs.push_back(sub);
+  }
   return srcfd::finish_create(m, out);
 }
 

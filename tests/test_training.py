@@ -25,6 +25,23 @@ def test_epoch_batches_partition_like_shuffle_batch():
     np.testing.assert_array_equal(merged, np.concatenate(b))
 
 
+def test_created_pair_saves_as_encoder_and_decoder_files(srcfd, tmp_path):
+    """A model built from layer specs (what training exports) writes the vanilla_encoder / vanilla_decoder pair."""
+    synth = importlib.import_module("sr-for-cfd_amd.synth")
+    enc, dec = synth.keras_default_init(3)
+    m = srcfd.SRModel.from_weights(enc, dec, device=-1)
+    e, d = str(tmp_path / "vanilla_encoder10_to_400_x.h5"), str(tmp_path / "vanilla_decoder400_from_10_x.h5")
+    m.save_h5(e, d)
+    me, md = srcfd.SRModel.load_h5(e, None, device=-1), srcfd.SRModel.load_h5(None, d, device=-1)
+    assert me.input_shape == (10, 10, 1) and me.output_shape == (1, 1, 50) and md.output_shape == (400, 400, 1)
+    both = srcfd.SRModel.load_h5(e, d, device=-1).weights()
+    for k, v in {**enc, **dec}.items():
+        np.testing.assert_array_equal(both[k], v)
+    # glorot limits: |w| <= sqrt(6 / (fan_in + fan_out)), zero biases
+    assert np.abs(enc["dense/kernel"]).max() <= np.sqrt(6.0 / (3200 + 128)) and not dec["dense_1/bias"].any()
+    assert np.abs(dec["conv2d_transpose/kernel"]).max() <= np.sqrt(6.0 / (9 * 128 + 9 * 256))
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -155,3 +172,32 @@ def test_fit_from_keras_default_init_on_the_dummy_recipe(srcfd):
     hist = tr.fit(t, xl, xh, epochs=4, batch_size=8, seed=0)
     assert len(hist) == 4 and all(np.isfinite(hist)) and hist[-1] < hist[0]
     assert 0.5 < hist[0] < 1.5  # unit-variance targets, near-zero initial prediction
+
+
+@pytest.mark.gpu
+def test_training_driver_end_to_end(srcfd, tmp_path):
+    """The notebook's __main__ (c374-604) in miniature: files -> split -> fit -> evaluate -> the three artefacts,
+    which then load through the same path the solvers use."""
+    require_gpu(srcfd)
+    import json
+    import subprocess
+    import sys
+    ds = importlib.import_module("sr-for-cfd_amd.datasets")
+    h5 = importlib.import_module("sr-for-cfd_amd.h5")
+    rng = np.random.default_rng(5)
+    w = h5.H5Writer()
+    for Re in (100, 200, 800):
+        base = {c: rng.standard_normal((400, 400)) for c in "uvp"}
+        ds.append_solution(w, Re, 400, base, "single_lid(u_top=1)")
+        ds.append_solution(w, Re, 10, {c: ds.avg_pool(base[c][None, ..., None].astype(np.float32), 40)[0, ..., 0] for c in "uvp"}, "single_lid(u_top=1)")
+    data = str(tmp_path / "simulation_result.h5")
+    w.save(data)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "sr-for-cfd_amd", "train_main.py"), "--data", data, "--epochs", "3", "--suffix", "t",
+                          "--out-dir", str(tmp_path), "--log-every", "0"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rep = json.loads(out.stdout.strip().splitlines()[-1])
+    assert rep["train_samples"] == 6 and len(rep["Re800"]["mae"]) == 3 and np.isfinite(rep["average_nmae_percent"])
+    enc, dec = str(tmp_path / "vanilla_encoder10_to_400_t.h5"), str(tmp_path / "vanilla_decoder400_from_10_t.h5")
+    lr, hr = srcfd.load_stats(str(tmp_path / "standardization_stats_10to400_t.txt"), 10, 400)
+    m = srcfd.SRModel.load_h5(enc, dec, device=0)
+    assert m.output_shape == (400, 400, 1) and all(np.isfinite(v) for c in "uvp" for v in lr[c] + hr[c])
