@@ -201,6 +201,24 @@ int srcfd_resample_device(srcfd_resampler* r, const float* in_dev, int n, double
 int srcfd_predict_resampled(srcfd_model* m, srcfd_resampler* r, const float* x, int n, const float* in_affine,
                             const float* out_affine, double* y, int flags, int64_t* n_nonfinite);
 
+/* ---- hand-off into the solver state ---------------------------------------------------------
+ * Replaces the three transposed assignments `solver.Var[k, 1:-1, 1:-1] = ml_initial_fields[c].T` and the
+ * ghost-cell pass `_apply_bc_wrapper(k)` that follow the SR call (PyCFD_ML_accelerated.py:936-943,
+ * bfs_ml_accelerated.py:1211-1218): x holds the u, v, p samples of ONE field; Var is the solver's
+ * float64 (3, nx+2, ny+2) host array and is written completely (corners 0, as in a fresh solver).
+ * bc[k]: apply_bc_configured's arrays (PyCFD_ML_accelerated.py:118-146), order left, right, top,
+ * bottom; type 0 = Dirichlet (ghost = 2*value - inner), 1 = Neumann (ghost = inner).  left_profile:
+ * optional [ny] Dirichlet values that override the left boundary row by row (the BFS inlet/wall mix,
+ * bfs_ml_accelerated.py:524-562).  r: optional resampler applied first (BFS), or NULL. */
+typedef struct srcfd_solver_bc {
+  int type[4];
+  double value[4];
+  const double* left_profile;
+} srcfd_solver_bc;
+int srcfd_predict_into_solver_state(srcfd_model* m, srcfd_resampler* r, const float* x, const float* in_affine,
+                                    const float* out_affine, const srcfd_solver_bc bc[3], double* Var, int flags,
+                                    int64_t* n_nonfinite);
+
 /* ---- training -----------------------------------------------------------
  * One optimisation step of SuperResolutionAE, split so that a data-parallel driver can put its
  * gradient all-reduce between the two halves (one flat f32 buffer per step).

@@ -340,3 +340,39 @@ def rel_l2(y: np.ndarray, ref: np.ndarray) -> float:
 
 MACS_PER_SAMPLE = 140_024_128  # SURVEY 8a totals
 FLOPS_PER_SAMPLE = 2 * MACS_PER_SAMPLE
+
+
+# ---------------------------------------------------------------------------
+# hand-off into the solver state (the step right after the SR call)
+# ---------------------------------------------------------------------------
+def inject_and_apply_bc(hr_fields, bc_types, bc_values, left_profiles=None):
+    """PyCFD_ML_accelerated.py:936-943: Var[k,1:-1,1:-1] = field.T on a zeroed (3,nx+2,ny+2) float64 state, then
+    `apply_bc_configured` (PyCFD...:118-146: left/right for j in 1..ny, top/bottom for i in 1..nx; Dirichlet
+    2*value - inner, Neumann = inner), then the BFS left-boundary override (bfs_ml_accelerated.py:524-562) when
+    `left_profiles[k]` (row-wise Dirichlet values) is given.  Plain loops, as the reference's njit code."""
+    ny, nx = np.asarray(hr_fields["u"]).shape
+    Var = np.zeros((3, nx + 2, ny + 2), np.float64)
+    for k, c in enumerate(("u", "v", "p")):
+        Var[k, 1:-1, 1:-1] = np.asarray(hr_fields[c]).T
+        t, v = bc_types[k], bc_values[k]
+        for j in range(1, ny + 1):
+            Var[k, 0, j] = 2 * v[0] - Var[k, 1, j] if t[0] == 0 else Var[k, 1, j]
+            Var[k, nx + 1, j] = 2 * v[1] - Var[k, nx, j] if t[1] == 0 else Var[k, nx, j]
+        for i in range(1, nx + 1):
+            Var[k, i, ny + 1] = 2 * v[2] - Var[k, i, ny] if t[2] == 0 else Var[k, i, ny]
+            Var[k, i, 0] = 2 * v[3] - Var[k, i, 1] if t[3] == 0 else Var[k, i, 1]
+        if left_profiles is not None and left_profiles.get(k) is not None:
+            for j in range(1, ny + 1):
+                Var[k, 0, j] = 2.0 * left_profiles[k][j - 1] - Var[k, 1, j]
+    return Var
+
+
+def bfs_inlet_profiles(ny, dy, step_height, h, Ub):
+    """bfs_ml_accelerated.py:524-562 as row-wise Dirichlet values for u (k=0) and v (k=1)."""
+    u = np.zeros(ny)
+    for j in range(1, ny + 1):
+        y = (j - 0.5) * dy
+        if y >= step_height:
+            yp = min(max(y - step_height, 0.0), h)
+            u[j - 1] = 6.0 * Ub * (yp / h) * (1.0 - (yp / h))
+    return {0: u, 1: np.zeros(ny)}

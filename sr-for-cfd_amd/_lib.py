@@ -39,6 +39,10 @@ class Layer(C.Structure):
     ]
 
 
+class SolverBC(C.Structure):
+    _fields_ = [("type", C.c_int * 4), ("value", C.c_double * 4), ("left_profile", C.POINTER(C.c_double))]
+
+
 def _load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise ImportError(
@@ -93,6 +97,7 @@ _protos = {
     "srcfd_resampler_destroy": (None, [_p]),
     "srcfd_resample_device": (C.c_int, [_p, _p, C.c_int, _p, _p]),
     "srcfd_predict_resampled": (C.c_int, [_p, _p, _p, C.c_int, _p, _p, _p, C.c_int, C.POINTER(C.c_int64)]),
+    "srcfd_predict_into_solver_state": (C.c_int, [_p, _p, _p, _p, _p, C.POINTER(SolverBC), _p, C.c_int, C.POINTER(C.c_int64)]),
     "srcfd_trainer_create": (C.c_int, [_p, C.c_int, C.POINTER(_p)]),
     "srcfd_trainer_destroy": (None, [_p]),
     "srcfd_trainer_num_params": (C.c_int64, [_p]),

@@ -114,6 +114,48 @@ struct Resampler {
   }
 };
 
+// ---------------------------------------------------------------------------
+// Hand-off into the solver state (PyCFD_ML_accelerated.py:936-943, bfs_ml_accelerated.py:1211-1218):
+//   Var[k, 1+i, 1+j] = field_k[j, i]                       (transposed injection, float64)
+//   ghost cells from apply_bc_configured (PyCFD...:118-146): Dirichlet 2*value - inner, Neumann = inner,
+//   left/right for j in 1..ny, then top/bottom for i in 1..nx; corners are never written (stay 0);
+//   optional per-row Dirichlet profile on the left boundary (BFS inlet/wall mix, bfs...:524-562).
+// One thread per Var element; same f64 expressions as the reference, so the result is bit-identical.
+// ---------------------------------------------------------------------------
+struct BcDev {
+  int type[3][4];
+  double value[3][4];
+  int has_profile[3];
+};
+
+template <typename T>
+__global__ void __launch_bounds__(256) solver_state_f64(const T* __restrict__ fields, int ny, int nx, BcDev bc, const double* __restrict__ left_profile,
+                                                         double* __restrict__ Var) {
+  const int64_t per = (int64_t)(nx + 2) * (ny + 2);
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 3 * per) return;
+  const int k = (int)(idx / per);
+  const int r = (int)(idx - (int64_t)k * per);
+  const int i = r / (ny + 2), j = r - i * (ny + 2);
+  const T* f = fields + (int64_t)k * ny * nx;
+  auto inner = [&](int ii, int jj) { return (double)f[(int64_t)(jj - 1) * nx + (ii - 1)]; };
+  const bool ib = i == 0 || i == nx + 1, jb = j == 0 || j == ny + 1;
+  double v = 0.0;
+  if (!ib && !jb) {
+    v = inner(i, j);
+  } else if (ib && !jb) {  // left / right
+    const int side = i == 0 ? 0 : 1;
+    const double in = inner(i == 0 ? 1 : nx, j);
+    if (side == 0 && bc.has_profile[k]) v = 2.0 * left_profile[(int64_t)k * ny + (j - 1)] - in;
+    else v = bc.type[k][side] == 0 ? 2 * bc.value[k][side] - in : in;
+  } else if (jb && !ib) {  // top / bottom
+    const int side = j == ny + 1 ? 2 : 3;
+    const double in = inner(i, j == 0 ? 1 : ny);
+    v = bc.type[k][side] == 0 ? 2 * bc.value[k][side] - in : in;
+  }
+  Var[idx] = v;
+}
+
 }  // namespace srcfd
 
 using srcfd::Resampler;
@@ -170,6 +212,61 @@ int srcfd_predict_resampled(srcfd_model* m, srcfd_resampler* r, const float* x, 
     HIPCHECK(hipMemcpyAsync(y + (size_t)first * rr->OH * rr->OW, rr->d_out, (size_t)count * rr->OH * rr->OW * sizeof(double), hipMemcpyDeviceToHost,
                             nullptr));
     return SRCFD_OK;
+  });
+}
+
+int srcfd_predict_into_solver_state(srcfd_model* m, srcfd_resampler* r, const float* x, const float* in_affine, const float* out_affine,
+                                    const srcfd_solver_bc bc[3], double* Var, int flags, int64_t* n_nonfinite) {
+  if (!m || !x || !bc || !Var) { set_error("srcfd_predict_into_solver_state: bad arguments"); return SRCFD_EINVAL; }
+  srcfd::Model* mm = reinterpret_cast<srcfd::Model*>(m);
+  Resampler* rr = reinterpret_cast<Resampler*>(r);
+  const int* os = mm->desc.out_shape();
+  if (os[2] != 1) { set_error("srcfd_predict_into_solver_state: single-channel models only"); return SRCFD_EINVAL; }
+  if (rr && (os[0] != rr->H || os[1] != rr->W || mm->device != rr->device)) {
+    set_error("srcfd_predict_into_solver_state: resampler does not match the model");
+    return SRCFD_EINVAL;
+  }
+  const int ny = rr ? rr->OH : os[0], nx = rr ? rr->OW : os[1];
+  srcfd::BcDev b{};
+  std::vector<double> prof((size_t)3 * ny, 0.0);
+  bool any_profile = false;
+  for (int k = 0; k < 3; ++k) {
+    for (int s = 0; s < 4; ++s) { b.type[k][s] = bc[k].type[s]; b.value[k][s] = bc[k].value[s]; }
+    b.has_profile[k] = bc[k].left_profile != nullptr;
+    if (bc[k].left_profile) { std::memcpy(&prof[(size_t)k * ny], bc[k].left_profile, sizeof(double) * ny); any_profile = true; }
+  }
+  const size_t var_elems = (size_t)3 * (nx + 2) * (ny + 2);
+  return mm->predict_host(x, 3, in_affine, out_affine, nullptr, flags, n_nonfinite, [&](const float* y_dev, int first, int count) -> int {
+    if (first != 0 || count != 3) { set_error("srcfd_predict_into_solver_state: internal chunking error"); return SRCFD_EINVAL; }
+    double* d_var = nullptr;
+    double* d_prof = nullptr;
+    HIPCHECK(hipMalloc(&d_var, var_elems * sizeof(double)));
+    int rc = SRCFD_OK;
+    do {
+      if (any_profile) {
+        if (hipMalloc(&d_prof, prof.size() * sizeof(double)) != hipSuccess ||
+            hipMemcpyAsync(d_prof, prof.data(), prof.size() * sizeof(double), hipMemcpyHostToDevice, nullptr) != hipSuccess) {
+          set_error("srcfd_predict_into_solver_state: profile upload failed"); rc = SRCFD_EHIP; break;
+        }
+      }
+      const unsigned blocks = (unsigned)((var_elems + 255) / 256);
+      if (rr) {
+        rc = rr->reserve(3);
+        if (rc) break;
+        rc = rr->run(y_dev, 3, rr->d_out, nullptr);
+        if (rc) break;
+        hipLaunchKernelGGL((srcfd::solver_state_f64<double>), dim3(blocks), dim3(256), 0, nullptr, rr->d_out, ny, nx, b, d_prof, d_var);
+      } else {
+        hipLaunchKernelGGL((srcfd::solver_state_f64<float>), dim3(blocks), dim3(256), 0, nullptr, y_dev, ny, nx, b, d_prof, d_var);
+      }
+      if (hipMemcpyAsync(Var, d_var, var_elems * sizeof(double), hipMemcpyDeviceToHost, nullptr) != hipSuccess ||
+          hipStreamSynchronize(nullptr) != hipSuccess) {
+        set_error("srcfd_predict_into_solver_state: copy back failed"); rc = SRCFD_EHIP;
+      }
+    } while (0);
+    (void)hipFree(d_var);
+    if (d_prof) (void)hipFree(d_prof);
+    return rc;
   });
 }
 

@@ -242,6 +242,52 @@ class SRModel:
                                               y.ctypes.data_as(C.c_void_p), L.FLAG_NAN_GUARD if nan_guard else 0, C.byref(bad)))
         return (y, int(bad.value)) if return_nonfinite else y
 
+    def predict_into_solver_state(self, x: np.ndarray, bc_types, bc_values, left_profiles=None, resampler=None, in_affine=None,
+                                  out_affine=None, nan_guard: bool = False, Var: Optional[np.ndarray] = None, return_nonfinite: bool = False):
+        """`predict` for the u, v, p samples of one field + the transposed float64 injection into the solver's
+        `Var (3, nx+2, ny+2)` + the ghost-cell pass, on the device (PyCFD_ML_accelerated.py:936-943).
+        bc_types (3,4) int [left,right,top,bottom] 0=Dirichlet 1=Neumann, bc_values (3,4); left_profiles: optional
+        {k: (ny,) float64} Dirichlet rows for the left boundary (BFS inlet, bfs_ml_accelerated.py:524-562)."""
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if x.shape[0] != 3 or tuple(x.shape[1:]) != self.input_shape:
+            raise ValueError(f"expected input (3,{self.input_shape}), got {x.shape}")
+        oh, ow, _ = self.output_shape
+        ny, nx = (resampler.out_h, resampler.out_w) if resampler is not None else (oh, ow)
+        bt = np.ascontiguousarray(bc_types, dtype=np.int32).reshape(3, 4)
+        bv = np.ascontiguousarray(bc_values, dtype=np.float64).reshape(3, 4)
+        arr = (L.SolverBC * 3)()
+        keep = []
+        for k in range(3):
+            for s_ in range(4):
+                arr[k].type[s_] = int(bt[k, s_])
+                arr[k].value[s_] = float(bv[k, s_])
+            prof = None if left_profiles is None else left_profiles.get(k)
+            if prof is not None:
+                prof = np.ascontiguousarray(prof, dtype=np.float64)
+                if prof.shape != (ny,):
+                    raise ValueError(f"left profile of variable {k} must have shape ({ny},)")
+                keep.append(prof)
+                arr[k].left_profile = prof.ctypes.data_as(C.POINTER(C.c_double))
+
+        def aff(a):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=np.float32)
+            if a.shape != (3, 2):
+                raise ValueError("affine must have shape (3, 2)")
+            return a
+        ai, ao = aff(in_affine), aff(out_affine)
+        if Var is None:
+            Var = np.empty((3, nx + 2, ny + 2), np.float64)
+        if Var.shape != (3, nx + 2, ny + 2) or Var.dtype != np.float64 or not Var.flags.c_contiguous:
+            raise ValueError(f"Var must be a C-contiguous float64 array of shape (3, {nx + 2}, {ny + 2})")
+        bad = C.c_int64(0)
+        L.check(L.lib.srcfd_predict_into_solver_state(self._h, resampler._h if resampler is not None else None, x.ctypes.data_as(C.c_void_p),
+                                                      ai.ctypes.data_as(C.c_void_p) if ai is not None else None,
+                                                      ao.ctypes.data_as(C.c_void_p) if ao is not None else None,
+                                                      arr, Var.ctypes.data_as(C.c_void_p), L.FLAG_NAN_GUARD if nan_guard else 0, C.byref(bad)))
+        return (Var, int(bad.value)) if return_nonfinite else Var
+
     def predict_device(self, x, y, in_affine=None, out_affine=None, nan_guard=False, nonfinite=None, stream=None):
         """Device-resident forward on torch CUDA tensors (plumbing only):
         x float32 (n,h,w,c); y float32/bfloat16/float16 (n,oh,ow,oc); affines

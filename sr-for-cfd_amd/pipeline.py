@@ -64,25 +64,18 @@ def reshape_square_to_rectangular(fields, nx_rect, ny_rect, lx, ly):
     return out
 
 
-def ml_super_resolution(coarse_fields: Dict[str, np.ndarray], lr_dim: int, hr_dim: int,
-                        stats_file: str, encoder_file: str, decoder_file: str,
-                        use_aspect_ratio_correction: bool = False, lx: float = 1.0, ly: float = 1.0,
-                        use_adaptive_normalization: bool = False, blend_factor: float = 0.3,
-                        precision: Optional[str] = None, verbose: bool = False) -> Dict[str, np.ndarray]:
-    """Lid-driven-cavity defaults (PyCFD_ML_accelerated.py:764); `ml_super_resolution_bfs`
-    has the backward-facing-step defaults.  Returns {'u','v','p'} -> (hr_dim, hr_dim) float32
-    (float64 after the BFS back-resampling, as scipy returns it)."""
-    say = print if verbose else (lambda *a, **k: None)
+def _prepare(coarse_fields, lr_dim, hr_dim, stats_file, encoder_file, decoder_file, use_aspect_ratio_correction, lx, ly,
+             use_adaptive_normalization, blend_factor, precision, say):
+    """Everything before `predict` (PyCFD...:787-857 / bfs...:1025-1108): model handle, the (3,lr,lr,1) float32
+    batch, the per-component (mean,std) pairs in and out, and the resampler for the way back (or None)."""
     fields = coarse_fields
     if use_aspect_ratio_correction and lx != ly:
         fields = reshape_rectangular_to_square(coarse_fields, lr_dim, lr_dim, lx, ly)
-
     stats_lr, stats_hr = load_stats(stats_file, lr_dim, hr_dim)  # FileNotFoundError / KeyError like :819-825
     for f in (encoder_file, decoder_file):  # the callers pre-check this (:1080-1087); load_model would raise too
         if not os.path.exists(f):
             raise FileNotFoundError(f"model file '{f}' not found")
     model = kc._device_handle((os.fspath(encoder_file), os.fspath(decoder_file)), precision or kc._DEFAULT_PRECISION)
-
     x = np.empty((3, lr_dim, lr_dim, 1), np.float32)
     ain = np.empty((3, 2), np.float32)
     aout = np.empty((3, 2), np.float32)
@@ -98,22 +91,85 @@ def ml_super_resolution(coarse_fields: Dict[str, np.ndarray], lr_dim: int, hr_di
         x[i, :, :, 0] = x_lr_raw
         ain[i] = (mean_lr, std_lr)
         aout[i] = stats_hr[c]
-
-    resample_back = use_aspect_ratio_correction and lx != ly
-    if resample_back:
+    back = None
+    if use_aspect_ratio_correction and lx != ly:
         from . import resample as rs
         back = rs.square_to_rect_resampler(hr_dim, hr_dim, hr_dim, float(lx), float(ly), model.device)
+    return model, x, ain, aout, back, fields
+
+
+def _warn_nonfinite(bad):
+    if bad:
+        warnings.warn(f"super-resolved fields contained {bad} NaN/Inf values; replaced with zeros "
+                      "(PyCFD_ML_accelerated.py:869-876)", RuntimeWarning)
+
+
+def ml_super_resolution(coarse_fields: Dict[str, np.ndarray], lr_dim: int, hr_dim: int,
+                        stats_file: str, encoder_file: str, decoder_file: str,
+                        use_aspect_ratio_correction: bool = False, lx: float = 1.0, ly: float = 1.0,
+                        use_adaptive_normalization: bool = False, blend_factor: float = 0.3,
+                        precision: Optional[str] = None, verbose: bool = False) -> Dict[str, np.ndarray]:
+    """Lid-driven-cavity defaults (PyCFD_ML_accelerated.py:764); `ml_super_resolution_bfs`
+    has the backward-facing-step defaults.  Returns {'u','v','p'} -> (hr_dim, hr_dim) float32
+    (float64 after the BFS back-resampling, as scipy returns it)."""
+    say = print if verbose else (lambda *a, **k: None)
+    model, x, ain, aout, back, fields = _prepare(coarse_fields, lr_dim, hr_dim, stats_file, encoder_file, decoder_file,
+                                                 use_aspect_ratio_correction, lx, ly, use_adaptive_normalization, blend_factor, precision, say)
+    if back is not None:
         y, bad = model.predict_resampled(x, back, in_affine=ain, out_affine=aout, nan_guard=True, return_nonfinite=True)
         y = y[..., None]
     else:
         y, bad = model.predict(x, in_affine=ain, out_affine=aout, nan_guard=True, return_nonfinite=True)
-    if bad:
-        warnings.warn(f"super-resolved fields contained {bad} NaN/Inf values; replaced with zeros "
-                      "(PyCFD_ML_accelerated.py:869-876)", RuntimeWarning)
+    _warn_nonfinite(bad)
     hr = {c: y[i, :, :, 0] for i, c in enumerate(COMPONENTS)}
     for c in COMPONENTS:
         say(f"  {c.upper()}: {fields[c].shape} -> {hr[c].shape}, range [{hr[c].min():.6f}, {hr[c].max():.6f}]")
     return hr
+
+
+def bc_arrays(bc):
+    """(3,4) int types and (3,4) float values, [left,right,top,bottom] for u, v, p, from the solvers'
+    `BoundaryConditions` object (`_get_bc_arrays`, PyCFD_ML_accelerated.py:~350 / bfs_ml_accelerated.py:497-521) or from a
+    plain {'u': {'left': ('dirichlet', 0.0), ...}, ...} dict."""
+    types = np.zeros((3, 4), np.int32)
+    values = np.zeros((3, 4), np.float64)
+    for k, c in enumerate(COMPONENTS):
+        d = getattr(bc, f"{c}_boundaries", None)
+        if d is None:
+            d = bc[c]
+        for s, side in enumerate(("left", "right", "top", "bottom")):
+            e = d[side]
+            t, v = (e.type, e.value) if hasattr(e, "type") else e
+            types[k, s] = 0 if t == "dirichlet" else 1
+            values[k, s] = v
+    return types, values
+
+
+def bfs_inlet_profiles(ny: int, dy: float, step_height: float, h: float, Ub: float) -> Dict[int, np.ndarray]:
+    """Row-wise Dirichlet values of the BFS left boundary (bfs_ml_accelerated.py:524-562): wall (0) below the step,
+    parabolic U = 6 Ub (y'/h)(1 - y'/h) above it with y' clamped to [0,h]; V = 0 everywhere."""
+    y = (np.arange(1, ny + 1) - 0.5) * dy
+    yp = np.clip(y - step_height, 0.0, h)
+    u = np.where(y < step_height, 0.0, 6.0 * Ub * (yp / h) * (1.0 - (yp / h)))
+    return {0: u, 1: np.zeros(ny)}
+
+
+def ml_super_resolution_into_solver(coarse_fields, lr_dim: int, hr_dim: int, stats_file: str, encoder_file: str, decoder_file: str, bc,
+                                    Var: Optional[np.ndarray] = None, left_profiles=None,
+                                    use_aspect_ratio_correction: bool = False, lx: float = 1.0, ly: float = 1.0,
+                                    use_adaptive_normalization: bool = False, blend_factor: float = 0.3,
+                                    precision: Optional[str] = None) -> np.ndarray:
+    """`ml_super_resolution` + the hand-off that follows it in the solvers (PyCFD_ML_accelerated.py:936-943,
+    bfs_ml_accelerated.py:1211-1218) as one device pass: returns/fills the float64 `Var (3, nx+2, ny+2)` with the SR
+    fields transposed into the interior and the ghost cells set from `bc`."""
+    model, x, ain, aout, back, _ = _prepare(coarse_fields, lr_dim, hr_dim, stats_file, encoder_file, decoder_file,
+                                            use_aspect_ratio_correction, lx, ly, use_adaptive_normalization, blend_factor, precision,
+                                            lambda *a, **k: None)
+    types, values = bc if isinstance(bc, tuple) else bc_arrays(bc)
+    Var, bad = model.predict_into_solver_state(x, types, values, left_profiles=left_profiles, resampler=back, in_affine=ain, out_affine=aout,
+                                               nan_guard=True, Var=Var, return_nonfinite=True)
+    _warn_nonfinite(bad)
+    return Var
 
 
 def ml_super_resolution_bfs(coarse_fields, lr_dim, hr_dim, stats_file, encoder_file, decoder_file,

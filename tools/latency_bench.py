@@ -54,6 +54,26 @@ def main():
         r = timeit(lambda: pl.ml_super_resolution_bfs(bfs, 10, 400, STATS, ENC, dec, use_aspect_ratio_correction=True, lx=10.0, ly=3.0,
                                                       precision=prec), args.calls)
         print(json.dumps({"call": "ml_super_resolution (BFS: spline resample + adaptive blend, bfs_ml_accelerated.py:979)", "precision": prec, **r}))
+    # the hand-off that follows the call in the solvers (PyCFD_ML_accelerated.py:936-943): host recipe vs one device pass
+    bc = {"u": {"left": ("dirichlet", 0.0), "right": ("dirichlet", 0.0), "top": ("dirichlet", 1.0), "bottom": ("dirichlet", 0.0)},
+          "v": {k: ("dirichlet", 0.0) for k in ("left", "right", "top", "bottom")},
+          "p": {k: ("neumann", 0.0) for k in ("left", "right", "top", "bottom")}}
+    types, values = pl.bc_arrays(bc)
+    Var = np.zeros((3, 402, 402))
+
+    def host_handoff():
+        hr = pl.ml_super_resolution(ldc, 10, 400, STATS, ENC, dec, precision="bf16")
+        pl.inject_into_solver_state(hr, Var)
+        for k in range(3):  # apply_bc_configured, vectorised
+            t, v = types[k], values[k]
+            Var[k, 0, 1:-1] = 2 * v[0] - Var[k, 1, 1:-1] if t[0] == 0 else Var[k, 1, 1:-1]
+            Var[k, -1, 1:-1] = 2 * v[1] - Var[k, -2, 1:-1] if t[1] == 0 else Var[k, -2, 1:-1]
+            Var[k, 1:-1, -1] = 2 * v[2] - Var[k, 1:-1, -2] if t[2] == 0 else Var[k, 1:-1, -2]
+            Var[k, 1:-1, 0] = 2 * v[3] - Var[k, 1:-1, 1] if t[3] == 0 else Var[k, 1:-1, 1]
+    r = timeit(host_handoff, args.calls)
+    print(json.dumps({"call": "ml_super_resolution + host injection into Var + ghost cells (numpy)", "precision": "bf16", **r}))
+    r = timeit(lambda: pl.ml_super_resolution_into_solver(ldc, 10, 400, STATS, ENC, dec, (types, values), Var=Var, precision="bf16"), args.calls)
+    print(json.dumps({"call": "ml_super_resolution_into_solver (fused device hand-off, float64 Var)", "precision": "bf16", **r}))
     # host-core stand-in for the reference's Keras call: the oracle's torch-CPU port, same pre/post
     import torch
     from oracle import sr_oracle as o
