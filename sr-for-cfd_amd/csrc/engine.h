@@ -44,6 +44,8 @@ struct Model {
   float* buf[2] = {nullptr, nullptr};
   int ws_chunk = 0;
   float* d_splitk = nullptr;  // split-K slabs of the skinny f32 GEMMs
+  double* d_solver_state = nullptr;  // (3, nx+2, ny+2) + row profiles of the solver hand-off
+  size_t solver_state_elems = 0;
   size_t splitk_floats = 0;
   float* d_x_stage = nullptr;
   float* d_y_stage = nullptr;

@@ -143,7 +143,8 @@ void Model::drop_graph() {
 
 void Model::free_workspace() {
   for (int i = 0; i < 2; ++i) if (buf[i]) { (void)hipFree(buf[i]); buf[i] = nullptr; }
-  for (void* p : {(void*)d_x_stage, (void*)d_y_stage, (void*)d_aff, (void*)d_nonfinite, (void*)d_splitk}) if (p) (void)hipFree(p);
+  for (void* p : {(void*)d_x_stage, (void*)d_y_stage, (void*)d_aff, (void*)d_nonfinite, (void*)d_splitk, (void*)d_solver_state}) if (p) (void)hipFree(p);
+  d_solver_state = nullptr; solver_state_elems = 0; d_splitk = nullptr; splitk_floats = 0;
   d_x_stage = d_y_stage = nullptr; d_aff = nullptr; d_nonfinite = nullptr;
   ws_chunk = 0; stage_chunk = 0;
 }

@@ -238,34 +238,29 @@ int srcfd_predict_into_solver_state(srcfd_model* m, srcfd_resampler* r, const fl
   const size_t var_elems = (size_t)3 * (nx + 2) * (ny + 2);
   return mm->predict_host(x, 3, in_affine, out_affine, nullptr, flags, n_nonfinite, [&](const float* y_dev, int first, int count) -> int {
     if (first != 0 || count != 3) { set_error("srcfd_predict_into_solver_state: internal chunking error"); return SRCFD_EINVAL; }
-    double* d_var = nullptr;
-    double* d_prof = nullptr;
-    HIPCHECK(hipMalloc(&d_var, var_elems * sizeof(double)));
+    const size_t need = var_elems + prof.size();
+    if (need > mm->solver_state_elems) {
+      if (mm->d_solver_state) { HIPCHECK(hipFree(mm->d_solver_state)); mm->d_solver_state = nullptr; mm->solver_state_elems = 0; }
+      HIPCHECK(hipMalloc(&mm->d_solver_state, need * sizeof(double)));
+      mm->solver_state_elems = need;
+    }
+    double* d_var = mm->d_solver_state;
+    double* d_prof = any_profile ? d_var + var_elems : nullptr;
+    if (any_profile) HIPCHECK(hipMemcpyAsync(d_prof, prof.data(), prof.size() * sizeof(double), hipMemcpyHostToDevice, nullptr));
+    const unsigned blocks = (unsigned)((var_elems + 255) / 256);
     int rc = SRCFD_OK;
-    do {
-      if (any_profile) {
-        if (hipMalloc(&d_prof, prof.size() * sizeof(double)) != hipSuccess ||
-            hipMemcpyAsync(d_prof, prof.data(), prof.size() * sizeof(double), hipMemcpyHostToDevice, nullptr) != hipSuccess) {
-          set_error("srcfd_predict_into_solver_state: profile upload failed"); rc = SRCFD_EHIP; break;
-        }
-      }
-      const unsigned blocks = (unsigned)((var_elems + 255) / 256);
-      if (rr) {
-        rc = rr->reserve(3);
-        if (rc) break;
-        rc = rr->run(y_dev, 3, rr->d_out, nullptr);
-        if (rc) break;
-        hipLaunchKernelGGL((srcfd::solver_state_f64<double>), dim3(blocks), dim3(256), 0, nullptr, rr->d_out, ny, nx, b, d_prof, d_var);
-      } else {
-        hipLaunchKernelGGL((srcfd::solver_state_f64<float>), dim3(blocks), dim3(256), 0, nullptr, y_dev, ny, nx, b, d_prof, d_var);
-      }
-      if (hipMemcpyAsync(Var, d_var, var_elems * sizeof(double), hipMemcpyDeviceToHost, nullptr) != hipSuccess ||
-          hipStreamSynchronize(nullptr) != hipSuccess) {
-        set_error("srcfd_predict_into_solver_state: copy back failed"); rc = SRCFD_EHIP;
-      }
-    } while (0);
-    (void)hipFree(d_var);
-    if (d_prof) (void)hipFree(d_prof);
+    if (rr) {
+      rc = rr->reserve(3);
+      if (rc) return rc;
+      rc = rr->run(y_dev, 3, rr->d_out, nullptr);
+      if (rc) return rc;
+      hipLaunchKernelGGL((srcfd::solver_state_f64<double>), dim3(blocks), dim3(256), 0, nullptr, rr->d_out, ny, nx, b, d_prof, d_var);
+    } else {
+      hipLaunchKernelGGL((srcfd::solver_state_f64<float>), dim3(blocks), dim3(256), 0, nullptr, y_dev, ny, nx, b, d_prof, d_var);
+    }
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipMemcpyAsync(Var, d_var, var_elems * sizeof(double), hipMemcpyDeviceToHost, nullptr));
+    HIPCHECK(hipStreamSynchronize(nullptr));
     return rc;
   });
 }
