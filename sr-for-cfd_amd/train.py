@@ -39,12 +39,19 @@ def epoch_batches(n_samples: int, batch_size: int, epoch: int, seed: int, rank_:
     """`Dataset.shuffle(len).batch(batch_size)` reshuffled every epoch (sr-ae-conv.ipynb:c558): a
     seeded permutation per epoch, cut into global batches of batch_size*world; each rank takes its
     contiguous slice of every global batch (the last one may be ragged, like Keras')."""
+    for idx, _ in epoch_batches_global(n_samples, batch_size, epoch, seed, rank_, world):
+        yield idx
+
+
+def epoch_batches_global(n_samples: int, batch_size: int, epoch: int, seed: int, rank_: int = 0, world: int = 1):
+    """As `epoch_batches`, yielding (this rank's indices, size of the global batch): every rank can
+    compute the loss normalisation without a collective."""
     perm = np.random.default_rng([seed, epoch]).permutation(n_samples)
     gb = batch_size * world
     for lo in range(0, n_samples, gb):
         idx = perm[lo:lo + gb]
         per = -(-len(idx) // world)
-        yield idx[rank_ * per:(rank_ + 1) * per]
+        yield idx[rank_ * per:(rank_ + 1) * per], len(idx)
 
 
 class Trainer:
@@ -102,9 +109,10 @@ class Trainer:
                                       C.c_void_p(self.v.data_ptr()), self.n_params, self.t, C.c_float(self.lr), C.c_float(self.beta1),
                                       C.c_float(self.beta2), C.c_float(self.eps), C.c_void_p(st.cuda_stream)))
 
-    def step(self, x, y, global_batch: Optional[int] = None) -> float:
+    def step(self, x, y, global_batch: Optional[int] = None, return_loss: bool = True):
         """One optimisation step on this rank's micro-batch (contiguous float32 CUDA tensors).  Returns
-        the global mean-squared error of the batch (like Keras' `recon_loss`)."""
+        the global mean-squared error of the batch (like Keras' `recon_loss`); with return_loss=False
+        nothing is read back (no host synchronisation) and the squared-error sum stays in `self.sse`."""
         import torch
         import torch.distributed as dist
         n = int(x.shape[0])
@@ -122,6 +130,8 @@ class Trainer:
             self.forward_backward(x, y, global_batch)
         allreduce_sum_(self.grads)
         self.apply_adam()
+        if not return_loss:
+            return None
         if w > 1:
             dist.all_reduce(self.sse)
         return float(self.sse.item()) / (global_batch * self.out_elems)
@@ -162,12 +172,19 @@ def fit(trainer: Trainer, x_lr: np.ndarray, x_hr: np.ndarray, epochs: int, batch
     xs = torch.from_numpy(np.ascontiguousarray(x_lr, np.float32)).to(trainer.device)
     ys = torch.from_numpy(np.ascontiguousarray(x_hr, np.float32)).to(trainer.device)
     history = []
+    epoch_loss = torch.zeros(1, dtype=torch.float64, device=trainer.device)
     for ep in range(epochs):
-        losses = []
-        for idx in epoch_batches(len(xs), batch_size, ep, seed, r, w):
+        epoch_loss.zero_()
+        steps = 0
+        for idx, gb in epoch_batches_global(len(xs), batch_size, ep, seed, r, w):
             sel = torch.from_numpy(np.ascontiguousarray(idx)).to(trainer.device)
-            losses.append(trainer.step(xs[sel].contiguous(), ys[sel].contiguous()))
-        history.append(float(np.mean(losses)))
+            trainer.step(xs[sel].contiguous(), ys[sel].contiguous(), global_batch=gb, return_loss=False)
+            epoch_loss += trainer.sse / (gb * trainer.out_elems)   # this rank's share of the batch loss, on the device
+            steps += 1
+        if w > 1:
+            import torch.distributed as dist
+            dist.all_reduce(epoch_loss)
+        history.append(float(epoch_loss.item()) / max(steps, 1))   # one read-back per epoch: mean of the batch losses
         if log_every and r == 0 and (ep + 1) % log_every == 0:
             print(f"epoch {ep + 1}: recon_loss {history[-1]:.6f}")
     return history
