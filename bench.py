@@ -109,8 +109,8 @@ def cpu_baseline(x, ain, aout, enc_w, dec_w, y_gpu_first, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "fp32"])
     ap.add_argument("--out-dtype", default="f32", choices=["f32", "bf16", "f16"])
     ap.add_argument("--fields", type=int, default=FIELDS)

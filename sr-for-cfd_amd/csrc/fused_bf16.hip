@@ -333,7 +333,7 @@ int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, cons
       mp.w1f = P.d_w1f;
       mp.b1f = P.d_midb + 128;
       { const char* e = getenv("SRCFD_MID_ABLATE"); mp.ablate = e ? atoi(e) : 0; }
-      const int mid_waves = [] { const char* e = getenv("SRCFD_MID_WAVES"); return e ? atoi(e) : 16; }();
+      const int mid_waves = [] { const char* e = getenv("SRCFD_MID_WAVES"); return e ? atoi(e) : 8; }();
       rc = m.launch("mid(convT0+convT1)", s, [&] { return launch_mid16(f16, mp, mid_waves, s); });
       if (rc) return rc;
     }

@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(256) enc_conv1_16(const float* __restrict__ x,
 constexpr int G_BP = 128, G_BK = 64, G_PITCH = 72;
 
 template <bool F16, int BN, bool SPLITK>
-__global__ void __launch_bounds__(256, 4) gemm16(GemmDesc d, const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wt, int Kpad,
+__global__ void __launch_bounds__(256, BN == 128 ? 3 : 4) gemm16(GemmDesc d, const uint16_t* __restrict__ X, const uint16_t* __restrict__ Wt, int Kpad,
                                                const float* __restrict__ bias, uint16_t* __restrict__ Y, float* __restrict__ part, int kslice) {
   constexpr int PT = BN == 128 ? 2 : 1;  // 32-pixel tiles per wave
   constexpr int WCH = BN / 64;           // 16-byte weight chunks per thread and k-tile
@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(256, 4) gemm16(GemmDesc d, const uint16_t* __r
   for (int j = 0; j < 2 * (BN / 64); ++j) woff[j] = (n0 + xrow + 32 * j) * Kpad + c8 * 8;
   const int lds_x = xrow * G_PITCH + c8 * 8;  // + 32j rows
 
-  uint4 xr[4], wr[WCH * 2];
+  uint4 xr[4], wr0, wr1, wr2 = make_uint4(0, 0, 0, 0), wr3 = make_uint4(0, 0, 0, 0);
   auto g2r = [&](int k0) {
     int tap = k0 / d.CI, ci0 = k0 - tap * d.CI;
     int ty = tap / d.TX, tx = tap - ty * d.TX;
@@ -137,16 +137,26 @@ __global__ void __launch_bounds__(256, 4) gemm16(GemmDesc d, const uint16_t* __r
         v = *reinterpret_cast<const uint4*>(X + (xoff[j] + toff));
       xr[j] = v;
     }
-#pragma unroll
-    for (int j = 0; j < WCH * 2; ++j) wr[j] = *reinterpret_cast<const uint4*>(Wt + (woff[j] + k0));
+    // named registers, not an array: the array form ended up in scratch (a store/load round trip right
+    // after every weight load, which serialised the prefetch)
+    wr0 = *reinterpret_cast<const uint4*>(Wt + (woff[0] + k0));
+    wr1 = *reinterpret_cast<const uint4*>(Wt + (woff[1] + k0));
+    if (WCH == 2) {
+      wr2 = *reinterpret_cast<const uint4*>(Wt + (woff[2 % (2 * WCH)] + k0));
+      wr3 = *reinterpret_cast<const uint4*>(Wt + (woff[3 % (2 * WCH)] + k0));
+    }
   };
   auto r2l = [&]() {
     uint16_t* xs = Xs + lds_x;
     uint16_t* ws = Ws + lds_x;
 #pragma unroll
     for (int j = 0; j < 4; ++j) *reinterpret_cast<uint4*>(xs + 32 * j * G_PITCH) = xr[j];
-#pragma unroll
-    for (int j = 0; j < WCH * 2; ++j) *reinterpret_cast<uint4*>(ws + 32 * j * G_PITCH) = wr[j];
+    *reinterpret_cast<uint4*>(ws) = wr0;
+    *reinterpret_cast<uint4*>(ws + 32 * G_PITCH) = wr1;
+    if (WCH == 2) {
+      *reinterpret_cast<uint4*>(ws + 64 * G_PITCH) = wr2;
+      *reinterpret_cast<uint4*>(ws + 96 * G_PITCH) = wr3;
+    }
   };
 
   f32x16 acc[2][PT];

@@ -41,7 +41,7 @@ template <int NW> struct MidCfg {
 };
 
 template <bool F16, int NW>
-__global__ void __launch_bounds__(64 * NW) mid16(MidParams p) {
+__global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
   using C = MidCfg<NW>;
   static_assert(C::OFF_META >= 32768 + NW * 32 * 144, "ConvT#1 operand half (32 KB) + per-wave store tiles are staged over the patch + weight tiles");
   extern __shared__ __attribute__((aligned(16))) char msm[];
@@ -90,27 +90,30 @@ __global__ void __launch_bounds__(64 * NW) mid16(MidParams p) {
   // staging roles: 16-byte column c8 of rows xrow + (NTHR/8)*j
   constexpr int RSTEP = C::NTHR / 8;
   const int xrow = tid >> 3, c8 = tid & 7;
-  uint4 wr[C::WCH], pr[C::PCH];
+  // native vector type: arrays of HIP's uint4 struct were left in scratch by the compiler (store/reload around every
+  // prefetch), which serialised the global loads
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 wr[C::WCH], pr[C::PCH];
   auto g2r_w = [&](int t, int c) {
 #pragma unroll
-    for (int j = 0; j < C::WCH; ++j) wr[j] = *reinterpret_cast<const uint4*>(Wt + (xrow + RSTEP * j) * Kp + t * 256 + c * 64 + c8 * 8);
+    for (int j = 0; j < C::WCH; ++j) wr[j] = *reinterpret_cast<const u32x4*>(Wt + (xrow + RSTEP * j) * Kp + t * 256 + c * 64 + c8 * 8);
   };
   auto g2r_p = [&](int c) {
 #pragma unroll
     for (int j = 0; j < C::PCH; ++j) {
       const int r = xrow + RSTEP * j;
-      pr[j] = r < NP ? *reinterpret_cast<const uint4*>(p.in + (size_t)(lo + r) * 256 + c * 64 + c8 * 8) : make_uint4(0, 0, 0, 0);
+      pr[j] = r < NP ? *reinterpret_cast<const u32x4*>(p.in + (size_t)(lo + r) * 256 + c * 64 + c8 * 8) : u32x4{0, 0, 0, 0};
     }
   };
   auto r2l_w = [&]() {
 #pragma unroll
-    for (int j = 0; j < C::WCH; ++j) *reinterpret_cast<uint4*>(Ws + (xrow + RSTEP * j) * M_PITCH + c8 * 8) = wr[j];
+    for (int j = 0; j < C::WCH; ++j) *reinterpret_cast<u32x4*>(Ws + (xrow + RSTEP * j) * M_PITCH + c8 * 8) = wr[j];
   };
   auto r2l_p = [&]() {
 #pragma unroll
     for (int j = 0; j < C::PCH; ++j) {
       const int r = xrow + RSTEP * j;
-      if (r < C::PATCH) *reinterpret_cast<uint4*>(Ps + r * M_PITCH + c8 * 8) = pr[j];
+      if (r < C::PATCH) *reinterpret_cast<u32x4*>(Ps + r * M_PITCH + c8 * 8) = pr[j];
     }
   };
 
