@@ -32,7 +32,7 @@ template <int NW> struct MidCfg {
   static constexpr int PATCH = (PX / 12 + 3) * 12 + 16;
   static constexpr int OFF_W = (PATCH + 1) * M_PITCH * 2;       // bytes; row PATCH is all zero
   static constexpr int MAIN_END = OFF_W + 128 * M_PITCH * 2;
-  static constexpr int T1_END = 32768 + NW * 32 * 144;          // ConvT#1 stage: operand half + per-wave store tiles
+  static constexpr int T1_END = 16384 + NW * 32 * 144;          // ConvT#1 stage: two operand tiles + per-wave store tiles
   static constexpr int OFF_META = MAIN_END > T1_END ? MAIN_END : T1_END;
   static constexpr int LDS = OFF_META + 3 * PX * 4;
   static constexpr int NTHR = 64 * NW;
@@ -43,7 +43,7 @@ template <int NW> struct MidCfg {
 template <bool F16, int NW>
 __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
   using C = MidCfg<NW>;
-  static_assert(C::OFF_META >= 32768 + NW * 32 * 144, "ConvT#1 operand half (32 KB) + per-wave store tiles are staged over the patch + weight tiles");
+  static_assert(C::OFF_META >= 16384 + NW * 32 * 144, "ConvT#1 operand tiles (2 x 8 KB) + per-wave store tiles are staged over the patch + weight tiles");
   extern __shared__ __attribute__((aligned(16))) char msm[];
   uint16_t* Ps = reinterpret_cast<uint16_t*>(msm);
   uint16_t* Ws = reinterpret_cast<uint16_t*>(msm + C::OFF_W);
@@ -105,6 +105,16 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
       pr[j] = r < NP ? *reinterpret_cast<const u32x4*>(p.in + (size_t)(lo + r) * 256 + c * 64 + c8 * 8) : u32x4{0, 0, 0, 0};
     }
   };
+  // ConvT#1 operand tiles (8 KB = 512 chunks of 16 B each, one per (tap, 32-channel half)) are double-buffered in
+  // LDS; the next tile is fetched into registers while the current one feeds the MFMAs
+  constexpr int W1CH = C::NTHR >= 512 ? 1 : 512 / C::NTHR;
+  u32x4 w1r[W1CH];
+  const u32x4* w1g = reinterpret_cast<const u32x4*>(p.w1f);
+  auto g2r_w1 = [&](int tile) {
+#pragma unroll
+    for (int j = 0; j < W1CH; ++j)
+      if (C::NTHR <= 512 || tid < 512) w1r[j] = w1g[tile * 512 + tid + C::NTHR * j];
+  };
   auto r2l_w = [&]() {
 #pragma unroll
     for (int j = 0; j < C::WCH; ++j) *reinterpret_cast<u32x4*>(Ws + (xrow + RSTEP * j) * M_PITCH + c8 * 8) = wr[j];
@@ -151,56 +161,59 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
   }
 
   // ---- ConvT#0 epilogue: swish, pack; the packed accumulators are ConvT#1's B operands ----
+  g2r_w1(0);  // ConvT#1's first operand tile is in flight during the swish below
   uint32_t fb[4][8];
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) swish_pack16<F16>(acc[mt], fb[mt]);
 
   // ---- ConvT#1: 8 tiles of 32 rows (tap = j8 >> 1, channels 32*(j8&1)..+31), K = 128 = 8 k-steps.
-  // Its 64 KB of A operands go through the (now free) LDS in two halves, shared by all waves.
+  // Its 64 KB of A operands go through the (now free) LDS one 8 KB tile at a time (double-buffered), shared by all waves.
   // Each tap's 32 pixels x 64 channels are transposed through a wave-private LDS tile so that the
   // global stores are whole 128-byte pixel rows (16 B per lane, 8 lanes per pixel) instead of
   // 8-byte pieces 512 B apart -- the scattered form was store-issue bound (~0.06 ms per batch).
-  const uint4* w1 = reinterpret_cast<const uint4*>(p.w1f);
-  uint4* w1s = reinterpret_cast<uint4*>(msm);
-  char* stage = msm + 32768 + wave * (32 * 144);  // [32 pixels][144 B]
+  uint4* w1s = reinterpret_cast<uint4*>(msm);          // two 8 KB operand tiles
+  char* stage = msm + 16384 + wave * (32 * 144);       // [32 pixels][144 B]
   const int Y = 2 * my + py, X = 2 * mx + px;  // 25x25-level pixel
   const int obase = img >= 0 ? ((img * 50 + 2 * Y) * 50 + 2 * X) * 64 : -1;  // element offset of tap (0,0)
-  if (!(p.ablate & 2))
-#pragma unroll 1
-  for (int half = 0; half < 2; ++half) {
+  auto r2l_w1 = [&](int buf) {
 #pragma unroll
-    for (int j = 0; j < 2048 / C::NTHR; ++j) w1s[tid + C::NTHR * j] = w1[half * 2048 + tid + C::NTHR * j];
+    for (int j = 0; j < W1CH; ++j)
+      if (C::NTHR <= 512 || tid < 512) reinterpret_cast<u32x4*>(w1s)[buf * 512 + tid + C::NTHR * j] = w1r[j];
+  };
+  if (!(p.ablate & 2)) {
+    r2l_w1(0);
     __syncthreads();
 #pragma unroll 1
-    for (int tl = 0; tl < 2; ++tl) {
-      const int tap = 2 * half + tl;
+    for (int jj = 0; jj < 8; ++jj) {
+      const int tap = jj >> 1, jh = jj & 1;
+      if (jj + 1 < 8) g2r_w1(jj + 1);
+      f32x16 a1 = load_bias16(reinterpret_cast<const char*>(p.b1f) + (jh * 2 + h) * 64);
+      const uint4* wt = w1s + (jj & 1) * 512 + lane;
 #pragma unroll
-      for (int jh = 0; jh < 2; ++jh) {
-        const int jj = 2 * tl + jh;
-        f32x16 a1 = load_bias16(reinterpret_cast<const char*>(p.b1f) + (jh * 2 + h) * 64);
+      for (int s = 0; s < 8; ++s) {
+        const uint4 wf = wt[s * 64];
+        const uint4 bf = make_uint4(fb[s >> 1][4 * (s & 1)], fb[s >> 1][4 * (s & 1) + 1], fb[s >> 1][4 * (s & 1) + 2], fb[s >> 1][4 * (s & 1) + 3]);
+        a1 = mfma32<F16>(wf, bf, a1);
+      }
+      uint32_t o[8];
+      swish_pack16<F16>(a1, o);
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-          const uint4 wf = w1s[(jj * 8 + s) * 64 + lane];
-          const uint4 bf = make_uint4(fb[s >> 1][4 * (s & 1)], fb[s >> 1][4 * (s & 1) + 1], fb[s >> 1][4 * (s & 1) + 2], fb[s >> 1][4 * (s & 1) + 3]);
-          a1 = mfma32<F16>(wf, bf, a1);
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<uint2*>(stage + l31 * 144 + 64 * jh + 16 * q + 8 * h) = make_uint2(o[2 * q], o[2 * q + 1]);
+      if (jh == 1) {
+        // coalesced write-out of this tap: lane -> (pixel = lane/8 + 8r, 16-byte chunk = lane%8)
+        const int toff = ((tap >> 1) * 50 + (tap & 1)) * 64;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int pix = (lane >> 3) + 8 * r;
+          const int ob = __shfl(obase, pix, 64);
+          const uint4 v = *reinterpret_cast<const uint4*>(stage + pix * 144 + (lane & 7) * 16);
+          if (ob >= 0) *reinterpret_cast<uint4*>(p.out + ob + toff + (lane & 7) * 8) = v;
         }
-        uint32_t o[8];
-        swish_pack16<F16>(a1, o);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          *reinterpret_cast<uint2*>(stage + l31 * 144 + 64 * jh + 16 * q + 8 * h) = make_uint2(o[2 * q], o[2 * q + 1]);
       }
-      // coalesced write-out of this tap: lane -> (pixel = lane/8 + 8r, 16-byte chunk = lane%8)
-      const int toff = ((tap >> 1) * 50 + (tap & 1)) * 64;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int pix = (lane >> 3) + 8 * r;
-        const int ob = __shfl(obase, pix, 64);
-        const uint4 v = *reinterpret_cast<const uint4*>(stage + pix * 144 + (lane & 7) * 16);
-        if (ob >= 0) *reinterpret_cast<uint4*>(p.out + ob + toff + (lane & 7) * 8) = v;
-      }
+      if (jj + 1 < 8) r2l_w1((jj + 1) & 1);
+      __syncthreads();
     }
-    __syncthreads();
   }
 }
 
