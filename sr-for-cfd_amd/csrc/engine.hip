@@ -236,6 +236,11 @@ int Model::forward_generic(const float* x_dev, int n, const float* aff_in, const
     float* Y = buf[cur ^ 1];
     const float* B = d_pack + op.w_off;
     const float* bias = d_pack + op.b_off;
+    if (!naive && i + 1 == ops.size() && gemm_fuses_finalize(d)) {  // last layer: epilogue writes the caller's buffer directly
+      return launch(op.name.c_str(), s, [&] {
+        return launch_gemm_finalize(d, X, B, bias, y_dev, out_dtype, aff_out, flags & SRCFD_FLAG_NAN_GUARD, nonfinite, s);
+      });
+    }
     rc = launch(op.name.c_str(), s, [&] { return naive ? launch_gemm_naive(d, X, B, bias, Y, s) : launch_gemm_mfma(d, X, B, bias, Y, s, d_splitk, splitk_floats); });
     if (rc) return rc;
   }

@@ -27,6 +27,10 @@ hipError_t launch_gemm_mfma(const GemmDesc& d, const float* X, const float* B, c
                             float* ws = nullptr, size_t ws_floats = 0);
 int gemm_splitk_splits(const GemmDesc& d, int* kchunk_out);
 size_t gemm_splitk_ws_floats(const GemmDesc& d);
+// Last layer + de-standardise + NaN guard + output cast in one kernel, for the layers gemm_fuses_finalize() accepts.
+bool gemm_fuses_finalize(const GemmDesc& d);
+hipError_t launch_gemm_finalize(const GemmDesc& d, const float* X, const float* B, const float* bias, void* out, int out_dtype,
+                                const float* affine, int nan_guard, unsigned long long* nonfinite, hipStream_t s);
 hipError_t launch_standardize(const float* x, float* y, const float* affine, int per_sample, int64_t total, hipStream_t s);
 hipError_t launch_finalize(const float* y, void* out, int out_dtype, const float* affine, int per_sample, int64_t total,
                            int nan_guard, unsigned long long* nonfinite, hipStream_t s);

@@ -343,6 +343,75 @@ __global__ void __launch_bounds__(256) conv_n1x4_f32(GemmDesc d, const float* __
                   act_apply_precise(acc[3], d.act));
 }
 
+// Same layer again, LDS-tiled: the per-pixel gathers above touch one 128-byte line per lane and load
+// instruction (the L1 tag rate, not HBM, bounds them at ~1.4 TB/s).  Here a workgroup stages an
+// (16+2) x (64+2)-pixel input tile with fully coalesced 16-byte loads, then one thread per output pixel
+// reads its 3x3x8 window from LDS (32-byte pixel pitch: 8 consecutive lanes cover all 64 banks).
+// FIN != 0: the network's last layer -- de-standardise, NaN/Inf guard and the output cast (finalize_out below,
+// same roundings) happen here instead of in a second pass over the image (FIN - 1 = output type: 0 f32, 1 bf16, 2 f16).
+struct FinalEpilogue {
+  void* out;
+  const float* affine;  // per-sample (mean, std) or nullptr
+  int nan_guard;
+  unsigned long long* nonfinite;
+};
+
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f);
+
+constexpr int CT_H = 16, CT_W = 64, CT_PW = CT_W + 2;
+template <int FIN>
+__global__ void __launch_bounds__(256) conv_n1_tile_f32(GemmDesc d, const float* __restrict__ X, const float* __restrict__ B,
+                                                         const float* __restrict__ bias, float* __restrict__ Y, FinalEpilogue fe) {
+  __shared__ float4 tile[(CT_H + 2) * CT_PW * 2];
+  __shared__ float w[72];
+  const int tid = threadIdx.x;
+  const int x0 = blockIdx.x * CT_W, y0 = blockIdx.y * CT_H, img = blockIdx.z;
+  if (tid < 72) w[tid] = B[(int64_t)tid * d.Npad];
+  // stage rows y0-1 .. y0+CT_H, pixels x0-1 .. x0+CT_W (zero outside the image = SAME padding)
+  const float4* src = reinterpret_cast<const float4*>(X + (int64_t)img * d.IH * d.IW * 8);
+  for (int e = tid; e < (CT_H + 2) * CT_PW * 2; e += 256) {
+    const int r = e / (CT_PW * 2), c = e - r * (CT_PW * 2), px = c >> 1, hf = c & 1;
+    const int iy = y0 - 1 + r, ix = x0 - 1 + px;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (iy >= 0 && iy < d.IH && ix >= 0 && ix < d.IW) v = src[((int64_t)iy * d.IW + ix) * 2 + hf];
+    tile[e] = v;
+  }
+  __syncthreads();
+  const int lx = tid & (CT_W - 1), ly0 = tid / CT_W;  // 4 rows per pass
+  const float b0 = bias[0];
+  const bool in_x = x0 + lx < d.OW;
+  float f_mean = 0.f, f_std = 1.f;
+  if (FIN && fe.affine) { f_mean = fe.affine[2 * img]; f_std = fe.affine[2 * img + 1]; }
+  unsigned nbad = 0;
+#pragma unroll
+  for (int pass = 0; pass < CT_H / 4; ++pass) {
+    const int ly = ly0 + 4 * pass;
+    if (!in_x || y0 + ly >= d.OH) continue;
+    float acc = b0;
+#pragma unroll
+    for (int ty = 0; ty < 3; ++ty)
+#pragma unroll
+      for (int tx = 0; tx < 3; ++tx) {
+        const float4 a = tile[((ly + ty) * CT_PW + lx + tx) * 2], c = tile[((ly + ty) * CT_PW + lx + tx) * 2 + 1];
+        const float* wp = w + (ty * 3 + tx) * 8;
+        acc = fmaf(a.x, wp[0], acc); acc = fmaf(a.y, wp[1], acc); acc = fmaf(a.z, wp[2], acc); acc = fmaf(a.w, wp[3], acc);
+        acc = fmaf(c.x, wp[4], acc); acc = fmaf(c.y, wp[5], acc); acc = fmaf(c.z, wp[6], acc); acc = fmaf(c.w, wp[7], acc);
+      }
+    float v = act_apply_precise(acc, d.act);
+    const int64_t o = ((int64_t)img * d.OH + y0 + ly) * d.OW + x0 + lx;
+    if (!FIN) { Y[o] = v; continue; }
+    if (fe.affine) v = __fadd_rn(__fmul_rn(v, f_std), f_mean);
+    if (fe.nan_guard && !(fabsf(v) <= 3.402823466e38f)) { ++nbad; v = 0.f; }
+    if (FIN == 1) reinterpret_cast<float*>(fe.out)[o] = v;
+    else if (FIN == 2) reinterpret_cast<unsigned short*>(fe.out)[o] = f32_to_bf16_bits(v);
+    else reinterpret_cast<_Float16*>(fe.out)[o] = (_Float16)v;
+  }
+  if (FIN && fe.nan_guard && fe.nonfinite) {  // every thread of the block reaches this point
+    for (int o = 32; o > 0; o >>= 1) nbad += __shfl_xor(nbad, o, 64);
+    if ((tid & 63) == 0 && nbad) atomicAdd(fe.nonfinite, (unsigned long long)nbad);
+  }
+}
+
 // single-input-channel conv with <= 8 output channels (the data gradient of `output_image_400`:
 // a 3x3 1->8 flipped-tap conv over 400x400): one thread per pixel, 8 accumulators, two 16-byte stores.
 __global__ void __launch_bounds__(256) conv_ci1_f32(GemmDesc d, const float* __restrict__ X, const float* __restrict__ B,
@@ -460,9 +529,34 @@ size_t gemm_splitk_ws_floats(const GemmDesc& d) {
   return splits > 1 ? (size_t)splits * d.M * d.Npad : 0;
 }
 
+static bool is_tiled_n1_conv(const GemmDesc& d) {
+  return d.N == 1 && d.nphx == 1 && d.TX == 3 && d.TY == 3 && d.CI == 8 && d.ax == 1 && d.bx == 1 && d.ay == 1 && d.by == 1 && d.cx == -1 &&
+         d.cy == -1 && d.os == 1 && d.ox0 == 0 && d.oy0 == 0 && d.OC == 1 && d.IH == d.OH && d.IW == d.OW && d.MH == d.OH && d.MW == d.OW &&
+         d.M > 0 && d.M % (d.MH * d.MW) == 0;
+}
+
+bool gemm_fuses_finalize(const GemmDesc& d) { return is_tiled_n1_conv(d); }
+
+hipError_t launch_gemm_finalize(const GemmDesc& d, const float* X, const float* B, const float* bias, void* out, int out_dtype,
+                                const float* affine, int nan_guard, unsigned long long* nonfinite, hipStream_t s) {
+  if (!is_tiled_n1_conv(d)) return hipErrorInvalidValue;
+  dim3 grid((d.OW + CT_W - 1) / CT_W, (d.OH + CT_H - 1) / CT_H, d.M / (d.MH * d.MW));
+  FinalEpilogue fe{out, affine, nan_guard, nonfinite};
+  if (out_dtype == SRCFD_F32) hipLaunchKernelGGL(conv_n1_tile_f32<1>, grid, dim3(256), 0, s, d, X, B, bias, nullptr, fe);
+  else if (out_dtype == SRCFD_BF16) hipLaunchKernelGGL(conv_n1_tile_f32<2>, grid, dim3(256), 0, s, d, X, B, bias, nullptr, fe);
+  else if (out_dtype == SRCFD_F16) hipLaunchKernelGGL(conv_n1_tile_f32<3>, grid, dim3(256), 0, s, d, X, B, bias, nullptr, fe);
+  else return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
 hipError_t launch_gemm_mfma(const GemmDesc& d, const float* X, const float* B, const float* bias, float* Y, hipStream_t s, float* ws,
                             size_t ws_floats) {
   if (d.M == 0 || d.N == 0) return hipSuccess;
+  if (is_tiled_n1_conv(d)) {
+    dim3 grid((d.OW + CT_W - 1) / CT_W, (d.OH + CT_H - 1) / CT_H, d.M / (d.MH * d.MW));
+    hipLaunchKernelGGL(conv_n1_tile_f32<0>, grid, dim3(256), 0, s, d, X, B, bias, Y, FinalEpilogue{});
+    return hipGetLastError();
+  }
   if (d.N == 1 && d.nphx == 1 && d.TX == 3 && d.TY == 3 && d.CI == 8 && d.ax == 1 && d.bx == 1 && d.ay == 1 && d.os == 1 && d.ox0 == 0 && d.OC == 1 &&
       d.MW % 4 == 0 && d.OW % 4 == 0 && d.K <= 512) {
     hipLaunchKernelGGL(conv_n1x4_f32, dim3((unsigned)((d.M / 4 + 255) / 256)), dim3(256), 0, s, d, X, B, bias, Y);
