@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsrcfd.so")
+LIB_PATH = os.environ.get("SRCFD_LIB") or os.path.join(_HERE, "lib", "libsrcfd.so")  # SRCFD_LIB: A/B builds of the same ABI
 
 OK, ENOENT, EIO, ENOMEM, ENODEV, EINVAL, EKEY, EHIP = 0, -2, -5, -12, -19, -22, -126, -1000
 

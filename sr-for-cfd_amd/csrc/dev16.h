@@ -44,6 +44,10 @@ __device__ __forceinline__ float act16(float u, int act) { return act == SRCFD_A
 // hipcc interleaves the four dependent steps of neighbouring elements, and with only four waves per
 // SIMD the in-order issue then stalls on every step (measured 25 cycles per 64 activations); in
 // batch order no instruction waits on one issued fewer than 16 slots earlier (~14 cycles).
+// Measured alternatives that did NOT help at this kernel's 4 waves per SIMD (tools/microbench4.hip, profiles/r01):
+// v_pk_add_f32 / v_pk_mul_f32 halve the instruction count but issue every 14 cycles per wave against 5.8 for the
+// plain forms; batches of 8 instead of 16 look 34 % faster when all waves run in lockstep and identical in the
+// real kernels, where the waves are in different phases.
 template <bool F16>
 __device__ __forceinline__ void swish_pack16(const f32x16& dd, uint32_t (&o)[8], bool skip = false) {
   if (skip) {

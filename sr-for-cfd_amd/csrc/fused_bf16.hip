@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -350,9 +351,22 @@ int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, cons
     tp.nonfinite = nonfinite;
     tp.out_dtype = out_dtype;
     { const char* e = getenv("SRCFD_TAIL_ABLATE"); tp.ablate = e ? atoi(e) : 0; }
+    static unsigned long long* d_prof = nullptr;   // SRCFD_TAIL_PROF=1: per-wave section timers of workgroup 0 (diagnostic)
+    static int prof_calls = 0;
+    const bool prof = getenv("SRCFD_TAIL_PROF") != nullptr;
+    if (prof && !d_prof) HIPCHECK(hipMalloc(&d_prof, 16 * 5 * sizeof(unsigned long long)));
+    tp.prof = prof ? d_prof : nullptr;
     const int blocks = std::min(c, fs->num_cus);
     rc = m.launch("tail(convT2-4+out)", s, [&] { return launch_tail16(f16, tp, blocks, s); });
     if (rc) return rc;
+    if (prof && ++prof_calls == 20) {
+      unsigned long long h[80];
+      HIPCHECK(hipStreamSynchronize(s));
+      HIPCHECK(hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost));
+      fprintf(stderr, "tail16 workgroup 0, cycles per wave: D, BC, A, barrier wait, total\n");
+      for (int w = 0; w < 16; ++w)
+        fprintf(stderr, "  wave %2d: %9llu %9llu %9llu %9llu %9llu\n", w, h[w * 5], h[w * 5 + 1], h[w * 5 + 2], h[w * 5 + 3], h[w * 5 + 4]);
+    }
   }
   return SRCFD_OK;
 }

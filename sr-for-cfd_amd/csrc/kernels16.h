@@ -28,7 +28,8 @@ struct TailParams {
   int nan_guard;
   unsigned long long* nonfinite;
   int out_dtype;
-  int ablate;              // diagnostic builds only (SRCFD_TAIL_ABLATE): 1 no swish, 2 no D, 4 no A, 8 no BC
+  int ablate;              // diagnostic (SRCFD_TAIL_ABLATE): 1 no swish, 2 no D, 4 no A, 8 no BC, 16 BC before D, 32 D before BC, 128 no priority raise
+  unsigned long long* prof;  // diagnostic (SRCFD_TAIL_PROF): per-wave cycle totals [block 0][16 waves][D, BC, A, barrier, total], else null
 };
 
 // ConvT#0 -> ConvT#1 fused kernel (kernels_mid16.hip)

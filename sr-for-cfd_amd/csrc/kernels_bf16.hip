@@ -302,7 +302,7 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
-template <bool F16, int OUT>  // OUT: 0 f32, 1 bf16, 2 f16
+template <bool F16, int OUT, bool PROF = false>  // OUT: 0 f32, 1 bf16, 2 f16; PROF: per-wave section timers (diagnostic)
 __global__ void __launch_bounds__(1024) tail16(TailParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
@@ -330,16 +330,24 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
     d_xo[cp] = 16 * (d_dx ? (cp < 4 ? 2 * cp * T_PLANE : 1) : (cp == 0 ? 7 * T_PLANE - 1 : (2 * cp - 1) * T_PLANE));
 
   // ---- static schedule (per round: 14 BC, 8 A, 16 D items over 16 waves) ----
+  // The kernel is VALU-issue bound and wave w runs on SIMD w % 4, so the schedule balances VALU instructions
+  // per SIMD (measured with SRCFD_TAIL_PROF: BC ~266, A ~92, D ~65 instructions; the last wave of a SIMD
+  // simply drains what the older waves leave): SIMD 0,1 get 4 BC + 2 A + 2 D, SIMD 2,3 get 3 BC + 2 A + 6 D.
   //   A : waves 0-7, item = wave; weights resident, activations prefetched one round ahead
-  //   BC: waves 8-15 -> item wave-8, waves 0-5 -> item 8+wave
-  //   D : waves 6,7 -> two items each; waves 8-11 -> two each; waves 12-15 -> one each
+  //   BC: waves 0,1,4,5,8,9,12,13 -> items 0-7; waves 2,3,6,7,10,11 -> items 8-13
+  //   D : waves 8,9,12,13 and 2,3,6,7 -> one item each (0-7); waves 10,11,14,15 -> two each (8-15)
   const bool hasA = wave < 8;
   const int a_mt = wave & 3, a_ct = (wave >> 2) & 1;
-  const int bc_item = wave >= 8 ? wave - 8 : (wave < 6 ? 8 + wave : -1);
-  int d_first = 0, d_cnt = 0;
-  if (wave == 6 || wave == 7) { d_first = 2 * (wave - 6); d_cnt = 2; }
-  else if (wave >= 8 && wave < 12) { d_first = 4 + 2 * (wave - 8); d_cnt = 2; }
-  else if (wave >= 12) { d_first = wave; d_cnt = 1; }
+  const int sq = wave >> 2, sl = wave & 3;       // wave = 4 * sq + sl, SIMD = sl
+  int bc_item = -1, d_first = 0, d_cnt = 0;
+  if (sl < 2) {                                   // SIMD 0,1
+    bc_item = 2 * sq + sl;                        // 0..7
+    if (sq >= 2) { d_first = 2 * (sq - 2) + sl; d_cnt = 1; }        // waves 8,9,12,13 -> 0..3
+  } else {                                        // SIMD 2,3
+    if (sq < 3) bc_item = 8 + 2 * sq + (sl - 2);  // waves 2,3,6,7,10,11 -> 8..13
+    if (sq < 2) { d_first = 4 + 2 * sq + (sl - 2); d_cnt = 1; }      // waves 2,3,6,7 -> 4..7
+    else { d_first = 8 + 4 * (sq - 2) + 2 * (sl - 2); d_cnt = 2; }   // waves 10,11,14,15 -> 8..15
+  }
 
   const int a_px = 32 * a_ct + l31;
   const bool a_valid = a_px < 50;
@@ -367,6 +375,8 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
   float o_mean = 0.f, o_std = 1.f, o_mean_prev = 0.f, o_std_prev = 1.f;  // de-standardisation of D's sample / the one before
   unsigned bad_count = 0;
 
+  unsigned long long tD = 0, tBC = 0, tA = 0, tBar = 0, tStart = 0, ts[6];
+  if (PROF) tStart = __builtin_amdgcn_s_memtime();
   for (int r = 0; r <= G + 2 && K > 0; ++r) {
     // ---------------- BC: ConvT#3 + ConvT#4 on 32 pixels of the 100-level ----------------
     auto do_bc = [&]() {
@@ -388,11 +398,11 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
       const int rbase = (8 * g) % T_RING_ROWS;  // tall-image row 8g
       const int rowv = rbase + 4 * a;
       char* wbase = ring + (((x100 & 1) * (4 * T_PLANE) + (x100 >> 1)) << 4) + 8 * h;
-      const f32x16 bias4 = load_bias16(cst + TC_OFF_B4 + h * 64);
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
         const int tap3 = 2 * m3 + tt, a3 = tap3 >> 1, b3 = tap3 & 1;
         uint4 bf = make_uint4(f3[4 * tt], f3[4 * tt + 1], f3[4 * tt + 2], f3[4 * tt + 3]);
+        const f32x16 bias4 = load_bias16(cst + TC_OFF_B4 + h * 64);  // re-read per tap: 16 registers less across the swish
         f32x16 acc4 = mfma32<F16>(w4, bf, bias4);
         uint32_t f4[8];
         swish_pack16<F16>(acc4, f4, ab_sw);
@@ -490,15 +500,24 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
       };
       // stagger: the BC-only-plus-D waves do their latency-bound D items first, so their VALU-heavy
       // BC items overlap the tail (A items) of the waves that started with BC
-      if (wave >= 8) {
+      if (PROF) ts[0] = __builtin_amdgcn_s_memtime();
+      const bool d_first_order = (p.ablate & 16) ? false : ((p.ablate & 32) ? true : wave >= 8);
+      if (d_first_order) {
+        if (!(p.ablate & 128)) __builtin_amdgcn_s_setprio(3);  // D is a latency chain with few instructions: let it through
         if (d_on && d_cnt >= 1) do_d(d_first);
         if (d_on && d_cnt >= 2) do_d(d_first + 1);
+        __builtin_amdgcn_s_setprio(0);
       }
+      if (PROF) ts[1] = __builtin_amdgcn_s_memtime();
       do_bc();
-      if (wave < 8) {
+      if (PROF) ts[2] = __builtin_amdgcn_s_memtime();
+      if (!d_first_order) {
+        if (!(p.ablate & 128)) __builtin_amdgcn_s_setprio(3);
         if (d_on && d_cnt >= 1) do_d(d_first);
         if (d_on && d_cnt >= 2) do_d(d_first + 1);
+        __builtin_amdgcn_s_setprio(0);
       }
+      if (PROF) ts[3] = __builtin_amdgcn_s_memtime();
     }
 
     // ---------------- A: ConvT#2 for strip g = r (input prefetched last round), then prefetch g+1 ----------------
@@ -521,7 +540,16 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
         for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(dst + l100_off(a, x100, q)) = make_uint2(f2[2 * q], f2[2 * q + 1]);
       }
     }
+    if (PROF) ts[4] = __builtin_amdgcn_s_memtime();
     lds_barrier();
+    if (PROF) {
+      ts[5] = __builtin_amdgcn_s_memtime();
+      tD += (ts[1] - ts[0]) + (ts[3] - ts[2]); tBC += ts[2] - ts[1]; tA += ts[4] - ts[3]; tBar += ts[5] - ts[4];
+    }
+  }
+  if (PROF && p.prof && blockIdx.x == 0 && lane == 0) {
+    unsigned long long* o = p.prof + wave * 5;
+    o[0] = tD; o[1] = tBC; o[2] = tA; o[3] = tBar; o[4] = __builtin_amdgcn_s_memtime() - tStart;
   }
   if (p.nan_guard && p.nonfinite && bad_count) atomicAdd(p.nonfinite, (unsigned long long)bad_count);
 }
@@ -587,7 +615,12 @@ hipError_t launch_tail16(bool f16, const TailParams& p, int blocks, hipStream_t 
   if (f16) { if (p.out_dtype == SRCFD_F32) PICK(true, 0); else if (p.out_dtype == SRCFD_BF16) PICK(true, 1); else PICK(true, 2); }
   else { if (p.out_dtype == SRCFD_F32) PICK(false, 0); else if (p.out_dtype == SRCFD_BF16) PICK(false, 1); else PICK(false, 2); }
 #undef PICK
+  if (p.prof && !f16 && p.out_dtype == SRCFD_F32) fn = tail16<false, 0, true>;
   int oi = p.out_dtype == SRCFD_F32 ? 0 : (p.out_dtype == SRCFD_BF16 ? 1 : 2);
+  if (p.prof) {  // diagnostic variant: set its attribute every time
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
+    if (e != hipSuccess) return e;
+  }
   if (!attr_done[f16 ? 1 : 0][oi]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
     if (e != hipSuccess) return e;
