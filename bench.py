@@ -125,11 +125,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: libsrcfd has no CPU fallback")
+    local_rank %= torch.cuda.device_count()   # rehearsals with more ranks than GPUs (SRCFD_BENCH_BACKEND=gloo) share devices
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("SRCFD_BENCH_BACKEND", "nccl")  # nccl = RCCL; gloo only to rehearse the rank logic on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     srcfd = importlib.import_module("sr-for-cfd_amd")
     synth = importlib.import_module("sr-for-cfd_amd.synth")
