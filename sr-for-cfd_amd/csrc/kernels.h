@@ -24,9 +24,10 @@ struct GemmDesc {
 hipError_t launch_gemm_naive(const GemmDesc& d, const float* X, const float* B, const float* bias, float* Y, hipStream_t s);
 // ws: optional split-K scratch (gemm_splitk_ws_floats(d) floats); without it the launch never splits.
 hipError_t launch_gemm_mfma(const GemmDesc& d, const float* X, const float* B, const float* bias, float* Y, hipStream_t s,
-                            float* ws = nullptr, size_t ws_floats = 0);
-int gemm_splitk_splits(const GemmDesc& d, int* kchunk_out);
-size_t gemm_splitk_ws_floats(const GemmDesc& d);
+                            float* ws = nullptr, size_t ws_floats = 0, bool batch_invariant = true);
+// batch_invariant (inference): the cut depends on the layer only, never on the batch size; false (training): on the tile count too.
+int gemm_splitk_splits(const GemmDesc& d, int* kchunk_out, bool batch_invariant = true);
+size_t gemm_splitk_ws_floats(const GemmDesc& d, bool batch_invariant = true);
 // Last layer + de-standardise + NaN guard + output cast in one kernel, for the layers gemm_fuses_finalize() accepts.
 bool gemm_fuses_finalize(const GemmDesc& d);
 hipError_t launch_gemm_finalize(const GemmDesc& d, const float* X, const float* B, const float* bias, void* out, int out_dtype,

@@ -512,10 +512,17 @@ hipError_t launch_gemm_naive(const GemmDesc& d, const float* X, const float* B, 
 
 // Skinny problems (few output tiles, long K: the Dense layers, and every layer at training batch
 // sizes) are cut along K so that the weight matrix is streamed by >= 256 blocks instead of 1-6.
-int gemm_splitk_splits(const GemmDesc& d, int* kchunk_out) {
+int gemm_splitk_splits(const GemmDesc& d, int* kchunk_out, bool batch_invariant) {
+  if (kchunk_out) *kchunk_out = d.K;
+  if (batch_invariant) {
+    // inference: the summation order of a sample must not depend on the batch it sits in, so the cut depends on the
+    // layer only: Dense layers (one row per sample) with a long K are always cut into 256-deep slabs
+    if (d.MH * d.MW != 1 || d.K < 1024 || d.M == 0) return 1;
+    if (kchunk_out) *kchunk_out = 256;
+    return (d.K + 255) / 256;
+  }
   int nb = (d.Npad % 128 == 0) ? 4 : ((d.Npad % 64 == 0) ? 2 : 1);
   int64_t tiles = (int64_t)((d.M + BM - 1) / BM) * (d.Npad / (32 * nb));
-  if (kchunk_out) *kchunk_out = d.K;
   if (tiles >= 128 || d.K < 256 || tiles == 0) return 1;
   int want = (int)std::min<int64_t>(std::min<int64_t>((512 + tiles - 1) / tiles, d.K / 64), 256);
   if (want <= 1) return 1;
@@ -524,8 +531,8 @@ int gemm_splitk_splits(const GemmDesc& d, int* kchunk_out) {
   return (d.K + kchunk - 1) / kchunk;
 }
 
-size_t gemm_splitk_ws_floats(const GemmDesc& d) {
-  int splits = gemm_splitk_splits(d, nullptr);
+size_t gemm_splitk_ws_floats(const GemmDesc& d, bool batch_invariant) {
+  int splits = gemm_splitk_splits(d, nullptr, batch_invariant);
   return splits > 1 ? (size_t)splits * d.M * d.Npad : 0;
 }
 
@@ -550,7 +557,7 @@ hipError_t launch_gemm_finalize(const GemmDesc& d, const float* X, const float* 
 }
 
 hipError_t launch_gemm_mfma(const GemmDesc& d, const float* X, const float* B, const float* bias, float* Y, hipStream_t s, float* ws,
-                            size_t ws_floats) {
+                            size_t ws_floats, bool batch_invariant) {
   if (d.M == 0 || d.N == 0) return hipSuccess;
   if (is_tiled_n1_conv(d)) {
     dim3 grid((d.OW + CT_W - 1) / CT_W, (d.OH + CT_H - 1) / CT_H, d.M / (d.MH * d.MW));
@@ -573,7 +580,7 @@ hipError_t launch_gemm_mfma(const GemmDesc& d, const float* X, const float* B, c
   const int vec = d.K <= 0 ? 0 : (d.CI % 16 == 0 ? 1 : (d.CI % 4 == 0 ? 2 : 0));
   int nb = (d.Npad % 128 == 0) ? 4 : ((d.Npad % 64 == 0) ? 2 : 1);
   int kchunk = d.K;
-  int splits = ws ? gemm_splitk_splits(d, &kchunk) : 1;
+  int splits = ws ? gemm_splitk_splits(d, &kchunk, batch_invariant) : 1;
   if (splits > 1 && (size_t)splits * d.M * d.Npad > ws_floats) splits = 1;
   float* wsp = splits > 1 ? ws : nullptr;
   dim3 grid((d.M + BM - 1) / BM, d.Npad / (32 * nb), splits);

@@ -619,8 +619,8 @@ static int trainer_build(Trainer& t, const Model& model, int max_batch) {
   HIPCHECK(hipMalloc(&t.d_loss_partial, 1024 * sizeof(double)));
   size_t sk = 0;
   for (int b = 1; b <= max_batch; ++b) {
-    for (const TrainOp& op : t.ops) { GemmDesc d = op.fwd; d.M = b * d.MH * d.MW; sk = std::max(sk, gemm_splitk_ws_floats(d)); }
-    for (const DgradOp& op : t.dops) { GemmDesc d = op.d; d.M = b * d.MH * d.MW; sk = std::max(sk, gemm_splitk_ws_floats(d)); }
+    for (const TrainOp& op : t.ops) { GemmDesc d = op.fwd; d.M = b * d.MH * d.MW; sk = std::max(sk, gemm_splitk_ws_floats(d, false)); }
+    for (const DgradOp& op : t.dops) { GemmDesc d = op.d; d.M = b * d.MH * d.MW; sk = std::max(sk, gemm_splitk_ws_floats(d, false)); }
   }
   t.splitk_floats = sk;
   if (sk) HIPCHECK(hipMalloc(&t.d_splitk, sk * sizeof(float)));
@@ -640,7 +640,7 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
     GemmDesc d = op.fwd;
     d.M = n * d.MH * d.MW;
     const float* X = op.layer == 0 ? x : t.Y[op.layer - 1];
-    HIPCHECK(launch_gemm_mfma(d, X, t.d_pack + op.w_off, t.d_pack + op.b_off, t.Z[op.layer], s, t.d_splitk, t.splitk_floats));
+    HIPCHECK(launch_gemm_mfma(d, X, t.d_pack + op.w_off, t.d_pack + op.b_off, t.Z[op.layer], s, t.d_splitk, t.splitk_floats, false));
     const bool last_of_layer = (&op == &t.ops.back()) || ((&op + 1)->layer != op.layer);
     if (last_of_layer && t.layers[op.layer].swish) {
       int64_t e = (int64_t)n * t.layers[op.layer].out_elems;
@@ -676,7 +676,7 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
       const DgradOp& dg = t.dops[li - 1];
       GemmDesc d = dg.d;
       d.M = n * d.MH * d.MW;
-      HIPCHECK(launch_gemm_mfma(d, dZ, t.d_dpack + dg.w_off, t.d_zero_bias, t.dbuf[cur ^ 1], s, t.d_splitk, t.splitk_floats));
+      HIPCHECK(launch_gemm_mfma(d, dZ, t.d_dpack + dg.w_off, t.d_zero_bias, t.dbuf[cur ^ 1], s, t.d_splitk, t.splitk_floats, false));
       cur ^= 1;
     }
   }

@@ -127,3 +127,36 @@ def test_bf16_in_affine_and_nan_guard(srcfd, enc_weights, dec_weights):
     xb[2, 3, 3, 0] = np.nan  # NaN input poisons the whole field through the dense layers
     yb, bad = m.predict(xb, nan_guard=True, return_nonfinite=True)
     assert bad == 160000 and np.all(yb[2] == 0) and np.isfinite(yb).all()
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_full_size_batch256_properties(srcfd, oracle, enc_weights, dec_weights, precision):
+    """BASELINE config 2 at its full size (256 fields = 768 samples) through the device entry point the bench uses.
+    The oracle needs ~1 s per sample, so the whole batch is checked through size-independent properties: samples are
+    independent (any permutation of the batch permutes the outputs bit for bit; a sub-batch reproduces its rows),
+    a duplicated input gives a duplicated output, and a handful of rows are compared with the float64 oracle."""
+    require_gpu(srcfd)
+    import torch
+    rng = np.random.default_rng(256)
+    n = 768
+    x = rng.standard_normal((n, 10, 10, 1)).astype(np.float32)
+    x[700] = x[3]  # duplicate
+    m = srcfd.SRModel.from_weights(enc_weights, dec_weights, device=0)
+    m.precision = precision
+    xd = torch.from_numpy(x).cuda()
+    y = torch.empty((n, 400, 400, 1), dtype=torch.float32, device="cuda")
+    m.predict_device(xd, y)
+    perm = torch.from_numpy(rng.permutation(n)).cuda()
+    yp = torch.empty_like(y)
+    m.predict_device(xd[perm].contiguous(), yp)
+    torch.cuda.synchronize()
+    assert torch.equal(yp, y[perm])
+    assert torch.equal(y[700], y[3])
+    ys = torch.empty((5, 400, 400, 1), dtype=torch.float32, device="cuda")
+    m.predict_device(xd[381:386].contiguous(), ys)
+    torch.cuda.synchronize()
+    assert torch.equal(ys, y[381:386])
+    idx = [0, 255, 511, 767]
+    tol = TOL["bf16"][1] if precision == "bf16" else 1e-5
+    assert oracle.rel_l2(y[idx].cpu().numpy(), oracle.superres_forward(x[idx], enc_weights, dec_weights, np.float64)) <= tol
+    assert bool(torch.isfinite(y).all())
