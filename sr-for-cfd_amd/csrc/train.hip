@@ -668,7 +668,7 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
       const int64_t elems = (int64_t)(d.K + 1) * d.Npad;
       if ((size_t)wp.nslices * elems > t.part_elems) { set_error("training: gradient slab buffer too small"); return SRCFD_EINVAL; }
       launch_wgrad(d, wp, X, dZ, t.d_part, s);
-      const int groups = wp.nslices >= 64 ? 8 : (wp.nslices >= 8 ? 4 : 1), epb = 256 / groups;
+      const int groups = wp.nslices >= 256 ? 32 : (wp.nslices >= 64 ? 8 : (wp.nslices >= 8 ? 4 : 1)), epb = 256 / groups;
       hipLaunchKernelGGL(wgrad_finish_f32, dim3((unsigned)((elems + epb - 1) / epb)), dim3(256), 0, s, t.d_part, wp.nslices, elems, op.d_gmap, grads,
                          d.K, d.N, d.Npad, d.CO, groups);
     }
