@@ -29,7 +29,7 @@ tolerances are stated against) or float32 (same-precision restatement).
 from __future__ import annotations
 
 import math
-from typing import Dict, Iterable, List, Optional, Sequence, Tuple
+from typing import Dict, Sequence, Tuple
 
 import numpy as np
 

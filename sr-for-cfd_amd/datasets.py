@@ -9,7 +9,6 @@ of length n*n (row-major (ny, nx)).
 """
 from __future__ import annotations
 
-import os
 import re
 from typing import Dict, Iterable, List, Sequence, Tuple, Union
 

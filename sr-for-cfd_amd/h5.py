@@ -8,7 +8,7 @@ float64 ``u,v,p,x,y``).
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List
 
 import numpy as np
 

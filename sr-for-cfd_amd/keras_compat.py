@@ -22,7 +22,7 @@ file pair and cached, instead of the reference's load-on-every-call.
 from __future__ import annotations
 
 import os
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 

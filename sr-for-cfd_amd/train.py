@@ -10,7 +10,7 @@ Adam update everywhere.  torch is used for device buffers and the
 from __future__ import annotations
 
 import ctypes as C
-from typing import Dict, Iterator, List, Optional, Tuple
+from typing import Dict, Iterator, List, Optional
 
 import numpy as np
 

@@ -1,7 +1,6 @@
 """Training-data I/O: simulation_result schema reader, per-BC Reynolds split,
 component-wise statistics and the stats-file writer, against plain numpy on the same arrays."""
 import importlib
-import os
 
 import numpy as np
 import pytest

@@ -4,9 +4,7 @@ import importlib
 import os
 import socket
 
-import numpy as np
 import pytest
-import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 

@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ENCODER_H5, GOLDEN, ROOT, STATS_TXT, require_gpu
+from conftest import ENCODER_H5, ROOT, STATS_TXT, require_gpu
 
 COMPAT = os.path.join(ROOT, "sr-for-cfd_amd", "compat")
 

@@ -2,7 +2,6 @@
 import ctypes
 import os
 import re
-import shutil
 import subprocess
 
 import numpy as np
