@@ -94,6 +94,14 @@ def cpu_baseline(x, ain, aout, enc_w, dec_w, y_gpu_first, budget_s=12.0):
         el = time.perf_counter() - t0
         if el >= budget_s:
             break
+    # the solver-side shape of the call (configs 1 and 3): three batch-1 predicts per field, like PyCFD_ML_accelerated.py:841-876
+    calls = []
+    for _ in range(7):
+        t1 = time.perf_counter()
+        for c in range(3):
+            xs1 = ((x[c:c + 1] - ain[c, 0]) / ain[c, 1]).astype(np.float32)
+            _ = model.forward(xs1, batch_size=1) * aout[c, 1] + aout[c, 0]
+        calls.append((time.perf_counter() - t1) * 1e3)
     y0 = y0 * aout[:bs, 1].reshape(-1, 1, 1, 1) + aout[:bs, 0].reshape(-1, 1, 1, 1)
     num = np.linalg.norm((y_gpu_first.astype(np.float64) - y0).reshape(bs, -1), axis=1)
     den = np.linalg.norm(y0.reshape(bs, -1).astype(np.float64), axis=1)
@@ -102,6 +110,7 @@ def cpu_baseline(x, ain, aout, enc_w, dec_w, y_gpu_first, budget_s=12.0):
         "sample": f"{done} single-channel samples ({done // 3} fields) in batches of 32, f32, torch-CPU/oneDNN port of the network "
                   f"(TensorFlow/Keras not installable; SURVEY.md 8c), {el:.1f} s",
         "host_cpus": os.cpu_count(),
+        "single_field_call_ms": round(float(np.median(calls)), 2),
         "gpu_vs_cpu_rel_l2_max": float(np.max(num / den)),
     }
 

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """BASELINE configs 1 and 3: latency of ONE `ml_super_resolution` call as the solvers make it
 (host numpy in, host numpy out, 3 components of one 10x10 field -> 400x400), end to end through the
-drop-in Python surface, next to the oracle's torch-CPU port of the same call on the host cores.
+drop-in Python surface.  (The host-core comparator for the same call is timed by bench.py's cpu_baseline leg,
+`single_field_call_ms`: only that leg may use oracle/.)
 
     python tools/latency_bench.py [--calls 50]
 Prints one JSON line per variant."""
@@ -74,25 +75,6 @@ def main():
     print(json.dumps({"call": "ml_super_resolution + host injection into Var + ghost cells (numpy)", "precision": "bf16", **r}))
     r = timeit(lambda: pl.ml_super_resolution_into_solver(ldc, 10, 400, STATS, ENC, dec, (types, values), Var=Var, precision="bf16"), args.calls)
     print(json.dumps({"call": "ml_super_resolution_into_solver (fused device hand-off, float64 Var)", "precision": "bf16", **r}))
-    # host-core stand-in for the reference's Keras call: the oracle's torch-CPU port, same pre/post
-    import torch
-    from oracle import sr_oracle as o
-    from oracle.sr_oracle_torch import TorchSR
-    enc_w = srcfd.SRModel.load_h5(ENC, None, device=-1).weights()
-    model = TorchSR(enc_w, dec_w, torch.float32)
-    stats = o.parse_stats(STATS)
-
-    def cpu_call():
-        out = {}
-        for c in "uvp":
-            x = np.asarray(ldc[c]).astype(np.float32)
-            x = (x - stats[f"mean10_{c}"]) / stats[f"std10_{c}"]
-            y = model.forward(x[None, :, :, None].astype(np.float32), batch_size=1)[0, :, :, 0]
-            out[c] = y * stats[f"std400_{c}"] + stats[f"mean400_{c}"]
-        return out
-    r = timeit(cpu_call, max(5, args.calls // 5), warm=2)
-    print(json.dumps({"call": "torch-CPU/oneDNN port of the same call (3 predicts of batch 1, like the reference)", "precision": "f32",
-                      "cores": int(torch.get_num_threads()), **r}))
 
 
 if __name__ == "__main__":
