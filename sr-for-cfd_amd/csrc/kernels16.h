@@ -3,6 +3,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <utility>
+#include <vector>
+
 #include "kernels.h"
 
 namespace srcfd {
@@ -17,6 +20,19 @@ constexpr int TC_OFF_B3 = TC_OFF_B2 + 128;
 constexpr int TC_OFF_B4 = TC_OFF_B3 + 128;
 constexpr int TC_OFF_BC = TC_OFF_B4 + 128;        // output-conv bias (f32) + padding
 constexpr int TAIL_CONST_BYTES = TC_OFF_BC + 16;
+
+// Raises a kernel's dynamic-LDS limit once per (kernel, device): the attribute is per device, and one process may
+// drive several GPUs through separate handles.
+inline hipError_t lds_attr_once(const void* fn, int bytes) {
+  static thread_local std::vector<std::pair<const void*, int>> done;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  for (auto& d : done) if (d.first == fn && d.second == dev) return hipSuccess;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) done.emplace_back(fn, dev);
+  return e;
+}
 
 struct TailParams {
   const uint16_t* in;      // (n,50,50,64) activations of ConvT#1, scaled by log2e

@@ -589,15 +589,11 @@ hipError_t launch_gemm16(bool f16, const GemmDesc& d, const uint16_t* X, const u
     case 6: fn = gemm16<true, 128, false>; break;
     default: fn = gemm16<true, 128, true>; break;
   }
-  static bool attr_done[8] = {};
   const int lds = gemm16_lds(bn);
-  if (!attr_done[slot]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    if (e != hipSuccess) return e;
-    attr_done[slot] = true;
-  }
+  hipError_t e = lds_attr_once(reinterpret_cast<const void*>(fn), lds);
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(fn, grid, dim3(256), lds, s, d, X, Wt, Kpad, bias, Y, part, kslice);
-  hipError_t e = hipGetLastError();
+  e = hipGetLastError();
   if (e != hipSuccess || !sk) return e;
   const int total = d.M * (d.N / 4);
   if (f16) hipLaunchKernelGGL(splitk_finish16<true>, dim3((total + 255) / 256), dim3(256), 0, s, part, nz, bias, Y, d.M, d.N, d.Npad, d.OC, d.act);
@@ -609,23 +605,14 @@ int tail_lds_bytes() { return T_LDS_BYTES; }
 
 hipError_t launch_tail16(bool f16, const TailParams& p, int blocks, hipStream_t s) {
   if (p.n == 0) return hipSuccess;
-  static bool attr_done[2][3] = {};
   void (*fn)(TailParams) = nullptr;
 #define PICK(F, O) fn = tail16<F, O>
   if (f16) { if (p.out_dtype == SRCFD_F32) PICK(true, 0); else if (p.out_dtype == SRCFD_BF16) PICK(true, 1); else PICK(true, 2); }
   else { if (p.out_dtype == SRCFD_F32) PICK(false, 0); else if (p.out_dtype == SRCFD_BF16) PICK(false, 1); else PICK(false, 2); }
 #undef PICK
   if (p.prof && !f16 && p.out_dtype == SRCFD_F32) fn = tail16<false, 0, true>;
-  int oi = p.out_dtype == SRCFD_F32 ? 0 : (p.out_dtype == SRCFD_BF16 ? 1 : 2);
-  if (p.prof) {  // diagnostic variant: set its attribute every time
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
-    if (e != hipSuccess) return e;
-  }
-  if (!attr_done[f16 ? 1 : 0][oi]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, T_LDS_BYTES);
-    if (e != hipSuccess) return e;
-    attr_done[f16 ? 1 : 0][oi] = true;
-  }
+  hipError_t e = lds_attr_once(reinterpret_cast<const void*>(fn), T_LDS_BYTES);
+  if (e != hipSuccess) return e;
   hipLaunchKernelGGL(fn, dim3(blocks), dim3(1024), T_LDS_BYTES, s, p);
   return hipGetLastError();
 }

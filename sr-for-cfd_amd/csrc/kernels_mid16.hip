@@ -220,13 +220,9 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
 template <bool F16, int NW>
 static hipError_t launch_mid16_nw(const MidParams& p, hipStream_t s) {
   using C = MidCfg<NW>;
-  static bool attr_done = false;
   void (*fn)(MidParams) = mid16<F16, NW>;
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-    if (e != hipSuccess) return e;
-    attr_done = true;
-  }
+  hipError_t e = lds_attr_once(reinterpret_cast<const void*>(fn), C::LDS);
+  if (e != hipSuccess) return e;
   const int blocks = (p.n * 169 + C::PX - 1) / C::PX;  // the largest phase (13x13 pixels per sample)
   hipLaunchKernelGGL(fn, dim3(blocks, 4), dim3(C::NTHR), C::LDS, s, p);
   return hipGetLastError();
