@@ -189,31 +189,40 @@ __global__ void __launch_bounds__(256, BN == 128 ? 3 : 4) gemm16(GemmDesc d, con
     __syncthreads();
   }
 
-  // epilogue: lane = pixel, 4 consecutive channels per register quad.  A wave's 32-channel
-  // group never straddles an output phase (CO is a multiple of 32 or there is one phase), so the
-  // phase offset is scalar and the store offset is pixel base + a compile-time channel step.
+  // epilogue.  In the accumulator layout a lane owns one pixel (row) and 4 consecutive channels per register quad;
+  // stored directly that is one 8-byte piece per lane, rows a whole pixel (or, for Dense layers, a whole sample)
+  // apart -- store-issue bound.  So the packed tile goes through LDS (the operand tiles are dead by now) and leaves
+  // as 16-byte chunks, 8 or 16 consecutive lanes per output row.
+  constexpr int SP = BN * 2 + 16;  // staging row pitch in bytes
+  char* stg = gsm;
+  if (SPLITK) {
 #pragma unroll
-  for (int b = 0; b < PT; ++b) {
-    const int prow = wp * 32 * PT + b * 32 + l31;
-    const int img = row_img[prow];
-    if (img < 0) continue;
-    const int pix = ((img * d.OH + row_my[prow] * d.os + d.oy0) * d.OW + row_mx[prow] * d.os + d.ox0) * d.OC;
+    for (int b = 0; b < PT; ++b) {
+      const int prow = wp * 32 * PT + b * 32 + l31;
+      if (row_img[prow] < 0) continue;
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
-      const int nb = n0 + wc * 64 + a * 32;  // wave-uniform
-      if (nb >= d.N) continue;
-      const int ph = nb / d.CO, co0 = nb - ph * d.CO;
-      const int py = ph / d.nphx, px = ph - py * d.nphx;
-      const int base = pix + (py * d.OW + px) * d.OC + co0 + 4 * h;
-      if (SPLITK) {
+      for (int a = 0; a < 2; ++a) {
+        const int nb = n0 + wc * 64 + a * 32;  // wave-uniform
+        if (nb >= d.N) continue;
         // one f32 slab per K slice, summed in slice order by splitk_finish16: reproducible bit for bit
         float* pp = part + ((int64_t)blockIdx.z * d.M + (m0 + prow)) * d.Npad + nb + 4 * h;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
           *reinterpret_cast<float4*>(pp + 8 * q) = make_float4(acc[a][b][4 * q], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]);
-        continue;
       }
+    }
+    return;
+  }
+#pragma unroll
+  for (int b = 0; b < PT; ++b) {
+    const int prow = wp * 32 * PT + b * 32 + l31;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int cb = wc * 64 + a * 32;       // channel offset inside the block tile, wave-uniform
+      const int nb = n0 + cb;
+      if (nb >= d.N) continue;
       const float* bp = bias + nb + 4 * h;
+      uint32_t o[8];
       if (d.act == SRCFD_ACT_SWISH) {
         f32x16 u;
 #pragma unroll
@@ -222,22 +231,34 @@ __global__ void __launch_bounds__(256, BN == 128 ? 3 : 4) gemm16(GemmDesc d, con
           u[4 * q] = acc[a][b][4 * q] + bv.x; u[4 * q + 1] = acc[a][b][4 * q + 1] + bv.y;
           u[4 * q + 2] = acc[a][b][4 * q + 2] + bv.z; u[4 * q + 3] = acc[a][b][4 * q + 3] + bv.w;
         }
-        uint32_t o[8];
         swish_pack16<F16>(u, o);
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-          if (nb + 8 * q + 4 * h < d.N) *reinterpret_cast<uint2*>(Y + (base + 8 * q)) = make_uint2(o[2 * q], o[2 * q + 1]);
       } else {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          if (nb + 8 * q + 4 * h >= d.N) continue;
           const float4 bv = *reinterpret_cast<const float4*>(bp + 8 * q);
-          uint2 o;
-          o.x = pack2<F16>(acc[a][b][4 * q] + bv.x, acc[a][b][4 * q + 1] + bv.y);
-          o.y = pack2<F16>(acc[a][b][4 * q + 2] + bv.z, acc[a][b][4 * q + 3] + bv.w);
-          *reinterpret_cast<uint2*>(Y + (base + 8 * q)) = o;
+          o[2 * q] = pack2<F16>(acc[a][b][4 * q] + bv.x, acc[a][b][4 * q + 1] + bv.y);
+          o[2 * q + 1] = pack2<F16>(acc[a][b][4 * q + 2] + bv.z, acc[a][b][4 * q + 3] + bv.w);
         }
       }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<uint2*>(stg + prow * SP + (cb + 8 * q + 4 * h) * 2) = make_uint2(o[2 * q], o[2 * q + 1]);
+    }
+  }
+  __syncthreads();
+  constexpr int CPR = BN / 8;  // 16-byte chunks per row
+#pragma unroll
+  for (int j = 0; j < G_BP * CPR / 256; ++j) {
+    const int e = tid + 256 * j, row = e / CPR, c = e - row * CPR;
+    const int img = row_img[row], n = n0 + 8 * c;
+    if (img < 0 || n >= d.N) continue;
+    const int ph = n / d.CO, co = n - ph * d.CO, py = ph / d.nphx, px = ph - py * d.nphx;
+    const int off = ((img * d.OH + row_my[row] * d.os + d.oy0 + py) * d.OW + row_mx[row] * d.os + d.ox0 + px) * d.OC + co;
+    const uint4 v = *reinterpret_cast<const uint4*>(stg + row * SP + c * 16);
+    if (n + 8 <= d.N && (off & 7) == 0) *reinterpret_cast<uint4*>(Y + off) = v;
+    else {
+      if (n + 4 <= d.N) *reinterpret_cast<uint2*>(Y + off) = make_uint2(v.x, v.y);
+      if (n + 8 <= d.N) *reinterpret_cast<uint2*>(Y + off + 4) = make_uint2(v.z, v.w);
     }
   }
 }
