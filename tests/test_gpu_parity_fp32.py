@@ -157,3 +157,66 @@ def test_empty_and_ragged_batches(srcfd, oracle, enc_weights):
         assert oracle.rel_l2(z, ref) <= TOL_FP32
     with pytest.raises(ValueError):
         m.predict(np.zeros((1, 9, 10, 1), np.float32))
+
+
+def test_random_layer_graphs(srcfd, oracle):
+    """Seeded fuzz over the generic f32 engine: random conv / transposed-conv / dense chains (odd sizes, channel counts that
+    are not multiples of the MFMA tile, strides 1-3, kernels 1-4, transposed convs with stride > kernel) against the float64 oracle, forward only (inference
+    engine; the trainer is checked on the reference architecture in test_training.py)."""
+    require_gpu(srcfd)
+    rng = np.random.default_rng(2024)
+    acts = ["swish", "linear", "relu", "tanh", "sigmoid"]
+    for trial in range(24):
+        h, w, c = int(rng.integers(3, 12)), int(rng.integers(3, 12)), int(rng.integers(1, 9))
+        specs, ref_ops = [], []
+        shape = (h, w, c)
+        n_layers = int(rng.integers(1, 4))
+        for li in range(n_layers):
+            kind = ["conv2d", "conv2d_transpose"][int(rng.integers(0, 2))]
+            k, s = int(rng.integers(1, 5)), int(rng.integers(1, 4))
+            cout = int(rng.integers(1, 20))
+            act = acts[int(rng.integers(0, len(acts)))]
+            cin = shape[2]
+            if kind == "conv2d":
+                same = bool(rng.integers(0, 2))
+                if not same and (shape[0] < k or shape[1] < k):
+                    same = True
+                wt = (rng.standard_normal((k, k, cin, cout)) / np.sqrt(k * k * cin)).astype(np.float32)
+                oh = -(-shape[0] // s) if same else (shape[0] - k) // s + 1
+                ow = -(-shape[1] // s) if same else (shape[1] - k) // s + 1
+            else:
+                same = False
+                wt = (rng.standard_normal((k, k, cout, cin)) / np.sqrt(cin)).astype(np.float32)
+                oh, ow = (shape[0] - 1) * s + k, (shape[1] - 1) * s + k
+            if oh * ow * cout > 40000:
+                break
+            b = (0.1 * rng.standard_normal(cout)).astype(np.float32)
+            specs.append(dict(kind=kind, k=k, stride=s, same=same, act=act, w=wt, b=b))
+            ref_ops.append((kind, wt, b, s, "same" if same else "valid", act))
+            shape = (oh, ow, cout)
+        if not specs:
+            continue
+        if rng.integers(0, 2):  # finish with flatten + dense
+            fin = shape[0] * shape[1] * shape[2]
+            dout = int(rng.integers(1, 70))
+            wd = (rng.standard_normal((fin, dout)) / np.sqrt(fin)).astype(np.float32)
+            bd = (0.1 * rng.standard_normal(dout)).astype(np.float32)
+            specs += [dict(kind="flatten"), dict(kind="dense", act="swish", w=wd, b=bd)]
+            ref_ops.append(("dense", wd, bd, 1, "", "swish"))
+        nb = int(rng.integers(1, 6))
+        x = rng.standard_normal((nb, h, w, c)).astype(np.float32)
+        ref = x.astype(np.float64)
+        for kind, wt, b, s, pad, act in ref_ops:
+            if kind == "conv2d":
+                ref = oracle.conv2d(ref, wt, b, s, pad, act)
+            elif kind == "conv2d_transpose":
+                ref = oracle.conv2d_transpose(ref, wt, b, s, "valid", act)
+            else:
+                ref = oracle.dense(ref.reshape(nb, -1), wt, b, act)
+        for prec in ("fp32", "fp32_naive"):
+            m = srcfd.SRModel.from_layers(specs, (h, w, c), device=0)
+            m.precision = prec
+            y = m.predict(x)
+            assert y.reshape(ref.shape).shape == ref.shape, (trial, prec)
+            err = oracle.rel_l2(y.reshape(nb, -1), ref.reshape(nb, -1))
+            assert err <= TOL_FP32, (trial, prec, err, [(o[0], o[1].shape, o[3], o[4], o[5]) for o in ref_ops])
