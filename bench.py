@@ -212,7 +212,7 @@ def main():
                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": n * 160000 * (2 + (4 if args.out_dtype == "f32" else 2)),
                         "avg_launch_ms": kernels[dom],
                         "algorithmic_flops_per_launch": fl,
-                        "note": "swish = 2 quarter-rate transcendentals per activation: the transcendental issue rate caps this network at ~0.40 of the MFMA peak (DESIGN.md 4.2)"}
+                        "note": "swish = 2 quarter-rate transcendentals per activation: exact swish caps this network at ~0.28 of the MFMA peak on the VALU transcendental rate (DESIGN.md 4.2)"}
         else:
             fl = 2.0 * MACS_PER_SAMPLE * n
             tot = sum(kernels.values())
