@@ -1,0 +1,15 @@
+import sys, importlib, time, numpy as np
+sys.path.insert(0, '/root/repo')
+srcfd = importlib.import_module('sr-for-cfd_amd'); synth = importlib.import_module('sr-for-cfd_amd.synth')
+enc = srcfd.SRModel.load_h5('/root/repo/tests/golden/vanilla_encoder10_to_400_swish_trained_upto_700_multiBC.h5', None, device=-1).weights()
+m = srcfd.SRModel.from_weights(enc, synth.synthetic_decoder_weights(1), device=0)
+for prec in ("bf16", "fp32"):
+    m.precision = prec
+    for n in (3, 48, 768):
+        x = np.random.default_rng(0).standard_normal((n, 10, 10, 1)).astype(np.float32)
+        m.predict(x)
+        t = []
+        for _ in range(5):
+            t0 = time.perf_counter(); y = m.predict(x); t.append(time.perf_counter() - t0)
+        dt = min(t)
+        print(f"{prec} host predict n={n}: {dt*1e3:.2f} ms -> {n/3/dt:.0f} fields/s, {y.nbytes/dt/1e9:.1f} GB/s out")
