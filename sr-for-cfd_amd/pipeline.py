@@ -187,11 +187,16 @@ def inject_into_solver_state(hr_fields: Dict[str, np.ndarray], Var: np.ndarray) 
         Var[k, 1:-1, 1:-1] = hr_fields[c].T
 
 
-def tiled_super_resolution(field: np.ndarray, model, lr_dim: int = 10, in_affine=None, out_affine=None) -> np.ndarray:
+def tiled_super_resolution(field: np.ndarray, model, lr_dim: int = 10, in_affine=None, out_affine=None, distributed: bool = False) -> np.ndarray:
     """BASELINE config 5: a (T*lr, T*lr, C) coarse field is cut into T x T non-overlapping
     lr x lr tiles, each component of each tile super-resolved independently with the same
     weights, and the 400x400 results stitched to (T*400, T*400, C).  No overlap or blending:
-    the reference defines none."""
+    the reference defines none.
+
+    distributed=True (inside an initialised `torch.distributed` group, one process per GPU): every rank
+    super-resolves its contiguous block of the T*T*C tile samples (shard.shard_range) and the blocks are
+    exchanged with one all_gather, so each rank returns the whole stitched field.  The tiles are independent:
+    there is no other collective."""
     H, W, C = field.shape
     ty, tx = H // lr_dim, W // lr_dim
     if ty * lr_dim != H or tx * lr_dim != W:
@@ -201,6 +206,28 @@ def tiled_super_resolution(field: np.ndarray, model, lr_dim: int = 10, in_affine
     n = tiles.shape[0]
     ai = np.tile(np.asarray(in_affine, np.float32), (ty * tx, 1)) if in_affine is not None else None
     ao = np.tile(np.asarray(out_affine, np.float32), (ty * tx, 1)) if out_affine is not None else None
-    y = model.predict(tiles, in_affine=ai, out_affine=ao)
+    if not distributed:
+        y = model.predict(tiles, in_affine=ai, out_affine=ao)
+    else:
+        import torch
+        import torch.distributed as dist
+        from .shard import shard_range
+        rank, world = dist.get_rank(), dist.get_world_size()
+        lo, hi = shard_range(n, rank, world)
+        y_loc = model.predict(tiles[lo:hi], in_affine=None if ai is None else ai[lo:hi], out_affine=None if ao is None else ao[lo:hi])
+        hr = y_loc.shape[1] if hi > lo else None
+        # blocks differ by at most one sample: pad to the largest, gather, cut
+        per = -(-n // world)
+        shape = torch.tensor([0 if hr is None else hr], dtype=torch.int64)
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+        shape = shape.to(dev)
+        dist.all_reduce(shape, op=dist.ReduceOp.MAX)
+        hr = int(shape.item())
+        buf = torch.zeros((per, hr, hr, 1), dtype=torch.float32, device=dev)
+        if hi > lo:
+            buf[:hi - lo] = torch.from_numpy(np.ascontiguousarray(y_loc)).to(dev)
+        parts = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(parts, buf)
+        y = np.concatenate([parts[r][:shard_range(n, r, world)[1] - shard_range(n, r, world)[0]].cpu().numpy() for r in range(world)])
     hr = y.shape[1]
     return y.reshape(ty, tx, C, hr, hr).transpose(0, 3, 1, 4, 2).reshape(ty * hr, tx * hr, C)
