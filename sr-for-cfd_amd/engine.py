@@ -190,8 +190,10 @@ class SRModel:
 
     # -- forward ------------------------------------------------------------
     def predict(self, x: np.ndarray, in_affine=None, out_affine=None, nan_guard: bool = False,
-                return_nonfinite: bool = False):
-        """numpy in / numpy out, like ``Model.predict`` (PyCFD...:858)."""
+                return_nonfinite: bool = False, out: Optional[np.ndarray] = None):
+        """numpy in / numpy out, like ``Model.predict`` (PyCFD...:858).  `out`: optional C-contiguous float32
+        (n, oh, ow, oc) array to fill instead of allocating (a fresh 491 MB result costs more in first-touch page
+        faults than in PCIe time; callers that predict repeatedly can reuse one)."""
         x = np.ascontiguousarray(x, dtype=np.float32)
         ih, iw, ic = self.input_shape
         if x.ndim == 2 and ih == 1 and iw == 1:
@@ -200,7 +202,12 @@ class SRModel:
             raise ValueError(f"input shape {x.shape} incompatible with model input (None, {ih}, {iw}, {ic})")
         n = x.shape[0]
         oh, ow, oc = self.output_shape
-        y = np.empty((n, oh, ow, oc), dtype=np.float32)
+        if out is None:
+            y = np.empty((n, oh, ow, oc), dtype=np.float32)
+        else:
+            if out.shape != (n, oh, ow, oc) or out.dtype != np.float32 or not out.flags.c_contiguous:
+                raise ValueError(f"out must be a C-contiguous float32 array of shape {(n, oh, ow, oc)}")
+            y = out
 
         def aff(a):
             if a is None:

@@ -220,3 +220,17 @@ def test_random_layer_graphs(srcfd, oracle):
             assert y.reshape(ref.shape).shape == ref.shape, (trial, prec)
             err = oracle.rel_l2(y.reshape(nb, -1), ref.reshape(nb, -1))
             assert err <= TOL_FP32, (trial, prec, err, [(o[0], o[1].shape, o[3], o[4], o[5]) for o in ref_ops])
+
+
+def test_predict_into_preallocated_output(srcfd, enc_weights):
+    require_gpu(srcfd)
+    m = srcfd.SRModel.from_weights(enc_weights, None, device=0)
+    x = np.random.default_rng(3).standard_normal((5, 10, 10, 1)).astype(np.float32)
+    y = m.predict(x)
+    buf = np.full_like(y, 7.0)
+    assert m.predict(x, out=buf) is buf
+    np.testing.assert_array_equal(buf, y)
+    with pytest.raises(ValueError):
+        m.predict(x, out=np.empty((4, 1, 1, 50), np.float32))
+    with pytest.raises(ValueError):
+        m.predict(x, out=np.empty((5, 1, 1, 50), np.float64))

@@ -13,3 +13,8 @@ for prec in ("bf16", "fp32"):
             t0 = time.perf_counter(); y = m.predict(x); t.append(time.perf_counter() - t0)
         dt = min(t)
         print(f"{prec} host predict n={n}: {dt*1e3:.2f} ms -> {n/3/dt:.0f} fields/s, {y.nbytes/dt/1e9:.1f} GB/s out")
+        t = []
+        for _ in range(5):
+            t0 = time.perf_counter(); m.predict(x, out=y); t.append(time.perf_counter() - t0)
+        dt = min(t)
+        print(f"{prec} host predict n={n} into a reused array: {dt*1e3:.2f} ms -> {n/3/dt:.0f} fields/s, {y.nbytes/dt/1e9:.1f} GB/s out")
