@@ -70,7 +70,12 @@ def _prepare(coarse_fields, lr_dim, hr_dim, stats_file, encoder_file, decoder_fi
     batch, the per-component (mean,std) pairs in and out, and the resampler for the way back (or None)."""
     fields = coarse_fields
     if use_aspect_ratio_correction and lx != ly:
-        fields = reshape_rectangular_to_square(coarse_fields, lr_dim, lr_dim, lx, ly)
+        # reshape_rectangular_to_square (bfs_ml_accelerated.py:59-101) as two cached 1-D spline matrices: the same
+        # interpolating bicubic spline as scipy's RectBivariateSpline to ~1e-15 (tests/test_resample.py), without three
+        # FITPACK fits per call
+        from . import resample as rs
+        Ry, Rx = rs.rect_to_square_matrices(lr_dim, lr_dim, float(lx), float(ly))
+        fields = {c: Ry @ np.asarray(coarse_fields[c], np.float64) @ Rx.T for c in COMPONENTS}
     stats_lr, stats_hr = load_stats(stats_file, lr_dim, hr_dim)  # FileNotFoundError / KeyError like :819-825
     for f in (encoder_file, decoder_file):  # the callers pre-check this (:1080-1087); load_model would raise too
         if not os.path.exists(f):
