@@ -356,7 +356,14 @@ int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, cons
     const bool prof = getenv("SRCFD_TAIL_PROF") != nullptr;
     if (prof && !d_prof) HIPCHECK(hipMalloc(&d_prof, 16 * 5 * sizeof(unsigned long long)));
     tp.prof = prof ? d_prof : nullptr;
-    const int blocks = std::min(c, fs->num_cus);
+    // small batches: cut each sample into as many segments as keep every CU at one workgroup or less
+    int seg = 1;
+    { const char* e = getenv("SRCFD_TAIL_SEG");
+      if (e) seg = atoi(e);
+      else for (int cand : {2, 5, 10, 25}) if (c * cand <= fs->num_cus) seg = cand; }
+    if (seg != 1 && seg != 2 && seg != 5 && seg != 10 && seg != 25) seg = 1;
+    tp.seg = seg;
+    const int blocks = std::min(c * seg, fs->num_cus);
     rc = m.launch("tail(convT2-4+out)", s, [&] { return launch_tail16(f16, tp, blocks, s); });
     if (rc) return rc;
     if (prof && ++prof_calls == 20) {

@@ -323,7 +323,7 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
-template <bool F16, int OUT, bool PROF = false>  // OUT: 0 f32, 1 bf16, 2 f16; PROF: per-wave section timers (diagnostic)
+template <bool F16, int OUT, bool PROF = false, bool SEG = false>  // OUT: 0 f32, 1 bf16, 2 f16; PROF: per-wave section timers (diagnostic); SEG: samples cut into segments
 __global__ void __launch_bounds__(1024) tail16(TailParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
@@ -379,11 +379,6 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
   if (hasA) {
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) wa[kk] = w2_f[(a_mt * 4 + kk) * 64 + lane];
-    if ((int)blockIdx.x < p.n) {
-      const uint16_t* src = p.in + ((size_t)blockIdx.x * 2500 + a_pxc) * 64 + 8 * h;
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) xb[kk] = *reinterpret_cast<const uint4*>(src + 16 * kk);
-    }
   }
 
   const bool ab_sw = p.ablate & 1;
@@ -391,8 +386,32 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
   // 400*K rows: strip g = 50*k + s.  Round r runs A(g=r), BC(g=r-1), D(g=r-2), so the pipeline never
   // drains between samples; D(g) covers rows 8g-1 .. 8g+6 of the tall image, and its first row pair at a
   // sample seam (last row of sample k-1, first row of sample k) is evaluated once per side of the seam.
-  const int K = ((int)blockIdx.x < p.n) ? (p.n - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
-  const int G = 50 * K;
+  // Small batches leave most CUs idle when a workgroup needs a whole sample, so a sample can be cut into S = p.seg
+  // segments of L = 50 / S strips ("virtual samples", id = sample * S + segment).  A segment is preceded by one
+  // warm-up strip (A and BC only) that refills the two ring rows its first output row pair reads; for segment 0 that
+  // strip lies above the image and is skipped (the top row pair takes zeros, as before).  S = 1 is the plain layout.
+  const int S = (SEG && p.seg > 1) ? p.seg : 1, L = 50 / S, SL = S > 1 ? L + 1 : 50;  // SEG == false: compile-time S = 1, the plain index math
+  const int NV = p.n * S;
+  const int K = ((int)blockIdx.x < NV) ? (NV - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+  const int G = SL * K;
+  // strip g of this workgroup's tall image -> (sample, actual strip s in -1..49)
+  auto strip_of = [&](const int g, int& smp, int& sidx, int& seg_out, int& sl_out) {
+    const int kv = g / SL, sl = g - SL * kv;
+    const int vs = (int)blockIdx.x + kv * (int)gridDim.x;
+    smp = vs / S;
+    const int seg = vs - smp * S;
+    sidx = S > 1 ? seg * L + sl - 1 : sl;
+    seg_out = seg; sl_out = sl;
+  };
+  if (hasA && K > 0) {
+    int smp0, s0, sg0, sl0;
+    strip_of(0, smp0, s0, sg0, sl0);
+    if (s0 >= 0) {
+      const uint16_t* src = p.in + (((size_t)smp0 * 50 + s0) * 50 + a_pxc) * 64 + 8 * h;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) xb[kk] = *reinterpret_cast<const uint4*>(src + 16 * kk);
+    }
+  }
   float o_mean = 0.f, o_std = 1.f, o_mean_prev = 0.f, o_std_prev = 1.f;  // de-standardisation of D's sample / the one before
   unsigned bad_count = 0;
 
@@ -403,6 +422,7 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
     auto do_bc = [&]() {
       const int g = r - 1;
       if (!(bc_item >= 0 && g >= 0 && g < G && !(p.ablate & 8))) return;
+      { int sm, sx, sg, sl; strip_of(g, sm, sx, sg, sl); if (sx < 0) return; }  // warm-up strip of a top segment: nothing above the image
       const int t = bc_item >> 1, m3 = bc_item & 1;
       int idx = 32 * t + l31;
       const bool valid = idx < 200;
@@ -443,20 +463,33 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
     // validity live in SGPRs and each lane only adds its own column offset.
     const int gd = r - 2;
     const bool d_on = gd >= 0 && !(p.ablate & 2);
-    const int kd = gd >= 0 ? gd / 50 : 0, sd = gd - 50 * kd;
-    const int sample_d = (int)blockIdx.x + kd * (int)gridDim.x;  // == p.n-range only while gd < G
-    if (d_on && sd == 0 && p.aff_out) {  // entering sample kd: rotate the de-standardisation scalars (SGPRs)
+    const int kd = gd >= 0 ? gd / SL : 0, sd = gd - SL * kd;   // virtual sample / local strip of D's strip
+    int sample_d = 0, s_d = 0, seg_d = 0, sl_d = 0;            // real sample and actual strip (valid while gd < G)
+    if (gd >= 0 && gd < G) strip_of(gd, sample_d, s_d, seg_d, sl_d);
+    // the virtual sample before this one (the last one, in the flush round) ended a real sample iff it was segment S-1
+    int prev_smp = 0; bool prev_ends = false;
+    if (gd >= 0 && sd == 0 && kd > 0) {
+      const int pv = (int)blockIdx.x + (kd - 1) * (int)gridDim.x;
+      prev_smp = pv / S;
+      prev_ends = pv - prev_smp * S == S - 1;
+    }
+    if (d_on && sd == 0 && p.aff_out) {  // entering a virtual sample: rotate the de-standardisation scalars (SGPRs)
       o_mean_prev = o_mean; o_std_prev = o_std;
       if (gd < G) {
         o_mean = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.aff_out[2 * sample_d])));
         o_std = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, p.aff_out[2 * sample_d + 1])));
       }
     }
+    const bool d_warm = gd == G || (S > 1 && sd == 0);   // no regular output rows: flush round, or a segment's warm-up strip
+    const bool d_top = !d_warm && s_d == 0;              // first strip of a real sample: row pair 0 = (nothing | row 0)
     {
       auto do_d = [&](const int item) {  // called (not looped) so no conservative vmcnt(0) lands in front of it
         const int rp = item >> 2, j4 = item & 3;
-        const bool seam = sd == 0 && rp == 0;          // row pair = (row 399 of sample kd-1, row 0 of sample kd)
-        if (gd == G && !seam) return;                  // flush round: only the last sample's row 399 is left
+        // rp == 0 at a boundary: the pair is (row 399 of the sample that just ended | row 0 of the one that starts)
+        const bool emit_prev = rp == 0 && sd == 0 && prev_ends;
+        const bool emit_top = rp == 0 && d_top;
+        const bool seam = emit_prev || emit_top || d_warm;
+        if (d_warm && !emit_prev) return;              // flush round / warm-up strip: at most the ended sample's row 399
         const int kg = lane >> 4;
         int tx = 16 * j4 + d_tsel;
         tx = tx < 50 ? tx : 49;
@@ -507,13 +540,13 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
         };
         if (!seam) {
           const f32x4 acc = conv(true, true);
-          store(acc, sample_d, 8 * sd - 1 + 2 * rp + oy, o_mean, o_std, true);
+          store(acc, sample_d, 8 * s_d - 1 + 2 * rp + oy, o_mean, o_std, true);
         } else {
-          if (kd > 0) {      // last row of the previous sample: rows 398,399 | zeros
+          if (emit_prev) {   // last row of the sample that ended: rows 398,399 | zeros
             const f32x4 acc = conv(true, false);
-            store(acc, sample_d - (int)gridDim.x, 399, o_mean_prev, o_std_prev, oy == 0);
+            store(acc, prev_smp, 399, o_mean_prev, o_std_prev, oy == 0);
           }
-          if (gd < G) {      // first row of this sample: zeros | rows 0,1
+          if (emit_top) {    // first row of this sample: zeros | rows 0,1
             const f32x4 acc = conv(false, true);
             store(acc, sample_d, 0, o_mean, o_std, oy == 1);
           }
@@ -542,13 +575,23 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
     }
 
     // ---------------- A: ConvT#2 for strip g = r (input prefetched last round), then prefetch g+1 ----------------
+    int a_smp = 0, a_s = -1, a_sg = 0, a_sl = 0;
+    if (r < G) strip_of(r, a_smp, a_s, a_sg, a_sl);
     if (hasA && r < G && !(p.ablate & 4)) {
+      int n_smp = 0, n_s = -1, n_sg = 0, n_sl = 0;
+      if (r + 1 < G) strip_of(r + 1, n_smp, n_s, n_sg, n_sl);
+      if (a_s < 0) {        // warm-up strip above the image: nothing to compute, only fetch the next strip's input
+        if (n_s >= 0) {
+          const uint16_t* src = p.in + (((size_t)n_smp * 50 + n_s) * 50 + a_pxc) * 64 + 8 * h;
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) xb[kk] = *reinterpret_cast<const uint4*>(src + 16 * kk);
+        }
+      } else {
       f32x16 acc = load_bias16(cst + TC_OFF_B2 + h * 64);
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) acc = mfma32<F16>(wa[kk], xb[kk], acc);
-      if (r + 1 < G) {
-        const int kn = (r + 1) / 50, sn = (r + 1) - 50 * kn;
-        const uint16_t* src = p.in + (((size_t)((int)blockIdx.x + kn * (int)gridDim.x) * 50 + sn) * 50 + a_pxc) * 64 + 8 * h;
+      if (n_s >= 0) {
+        const uint16_t* src = p.in + (((size_t)n_smp * 50 + n_s) * 50 + a_pxc) * 64 + 8 * h;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) xb[kk] = *reinterpret_cast<const uint4*>(src + 16 * kk);
       }
@@ -559,6 +602,7 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
         char* dst = l100 + (r & 1) * T_L100_BUF + 8 * h;
 #pragma unroll
         for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(dst + l100_off(a, x100, q)) = make_uint2(f2[2 * q], f2[2 * q + 1]);
+      }
       }
     }
     if (PROF) ts[4] = __builtin_amdgcn_s_memtime();
@@ -627,11 +671,12 @@ int tail_lds_bytes() { return T_LDS_BYTES; }
 hipError_t launch_tail16(bool f16, const TailParams& p, int blocks, hipStream_t s) {
   if (p.n == 0) return hipSuccess;
   void (*fn)(TailParams) = nullptr;
-#define PICK(F, O) fn = tail16<F, O>
+  const bool seg = p.seg > 1;
+#define PICK(F, O) fn = seg ? tail16<F, O, false, true> : tail16<F, O, false, false>
   if (f16) { if (p.out_dtype == SRCFD_F32) PICK(true, 0); else if (p.out_dtype == SRCFD_BF16) PICK(true, 1); else PICK(true, 2); }
   else { if (p.out_dtype == SRCFD_F32) PICK(false, 0); else if (p.out_dtype == SRCFD_BF16) PICK(false, 1); else PICK(false, 2); }
 #undef PICK
-  if (p.prof && !f16 && p.out_dtype == SRCFD_F32) fn = tail16<false, 0, true>;
+  if (p.prof && !f16 && p.out_dtype == SRCFD_F32) fn = seg ? tail16<false, 0, true, true> : tail16<false, 0, true, false>;
   hipError_t e = lds_attr_once(reinterpret_cast<const void*>(fn), T_LDS_BYTES);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(fn, dim3(blocks), dim3(1024), T_LDS_BYTES, s, p);

@@ -9,6 +9,7 @@
 // 400x400 field on the host, which is ~97 % of the reference BFS call once the network runs on the GPU.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -29,8 +30,8 @@ namespace srcfd {
 
 // C[z] (M x N) = A[z] (M x K) * B[z] (K x N), row-major, f64 FMA in ascending k.
 // 64 x 64 tile per 256-thread block, 4 x 4 outputs per thread, 16-deep k slabs in LDS.
-template <typename TA>
-__global__ void __launch_bounds__(256) gemm_f64(const TA* __restrict__ A, int64_t strideA, const double* __restrict__ B, int64_t strideB,
+template <typename TA, typename TB>
+__global__ void __launch_bounds__(256) gemm_f64(const TA* __restrict__ A, int64_t strideA, const TB* __restrict__ B, int64_t strideB,
                                                  double* __restrict__ C, int64_t strideC, int M, int N, int K) {
   __shared__ double As[16][65];
   __shared__ double Bs[16][64];
@@ -51,7 +52,7 @@ __global__ void __launch_bounds__(256) gemm_f64(const TA* __restrict__ A, int64_
       int m = e >> 4, kk = e & 15;
       As[kk][m] = (m0 + m < M && k0 + kk < K) ? (double)A[(int64_t)(m0 + m) * K + k0 + kk] : 0.0;
       int kb = e >> 6, nn = e & 63;
-      Bs[kb][nn] = (k0 + kb < K && n0 + nn < N) ? B[(int64_t)(k0 + kb) * N + n0 + nn] : 0.0;
+      Bs[kb][nn] = (k0 + kb < K && n0 + nn < N) ? (double)B[(int64_t)(k0 + kb) * N + n0 + nn] : 0.0;
     }
     __syncthreads();
 #pragma unroll
@@ -80,6 +81,11 @@ __global__ void __launch_bounds__(256) gemm_f64(const TA* __restrict__ A, int64_
   }
 }
 
+__global__ void __launch_bounds__(256) widen_f64(const float* __restrict__ x, double* __restrict__ y, int64_t n) {
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = (double)x[i];
+}
+
 struct Resampler {
   int device = 0;
   int H = 0, W = 0, OH = 0, OW = 0;
@@ -101,14 +107,26 @@ struct Resampler {
     cap = n;
     return SRCFD_OK;
   }
-  // out[z] = Ry * (in[z] * Rx^T); both on `s`
+  // out[z] = Ry * (in[z] * Rx^T) on `s`.  A factor that is the identity (the BFS case lx = max(lx, ly): the square and
+  // the rectangle share their x nodes) is skipped: one GEMM instead of two.
+  bool rx_identity = false, ry_identity = false;
   int run(const float* in_dev, int n, double* out_dev, hipStream_t s) {
     int rc = reserve(n);
     if (rc) return rc;
-    hipLaunchKernelGGL((gemm_f64<float>), dim3((OW + 63) / 64, (H + 63) / 64, n), dim3(256), 0, s, in_dev, (int64_t)H * W, d_RxT, (int64_t)0, d_T,
-                       (int64_t)H * OW, H, OW, W);
-    hipLaunchKernelGGL((gemm_f64<double>), dim3((OW + 63) / 64, (OH + 63) / 64, n), dim3(256), 0, s, d_Ry, (int64_t)0, d_T, (int64_t)H * OW, out_dev,
-                       (int64_t)OH * OW, OH, OW, H);
+    if (rx_identity && ry_identity) {
+      hipLaunchKernelGGL(widen_f64, dim3((unsigned)(((int64_t)n * H * W + 255) / 256)), dim3(256), 0, s, in_dev, out_dev, (int64_t)n * H * W);
+    } else if (rx_identity) {
+      hipLaunchKernelGGL((gemm_f64<double, float>), dim3((W + 63) / 64, (OH + 63) / 64, n), dim3(256), 0, s, d_Ry, (int64_t)0, in_dev, (int64_t)H * W, out_dev,
+                         (int64_t)OH * W, OH, W, H);
+    } else if (ry_identity) {
+      hipLaunchKernelGGL((gemm_f64<float, double>), dim3((OW + 63) / 64, (H + 63) / 64, n), dim3(256), 0, s, in_dev, (int64_t)H * W, d_RxT, (int64_t)0, out_dev,
+                         (int64_t)H * OW, H, OW, W);
+    } else {
+      hipLaunchKernelGGL((gemm_f64<float, double>), dim3((OW + 63) / 64, (H + 63) / 64, n), dim3(256), 0, s, in_dev, (int64_t)H * W, d_RxT, (int64_t)0, d_T,
+                         (int64_t)H * OW, H, OW, W);
+      hipLaunchKernelGGL((gemm_f64<double, double>), dim3((OW + 63) / 64, (OH + 63) / 64, n), dim3(256), 0, s, d_Ry, (int64_t)0, d_T, (int64_t)H * OW, out_dev,
+                         (int64_t)OH * OW, OH, OW, H);
+    }
     HIPCHECK(hipGetLastError());
     return SRCFD_OK;
   }
@@ -178,6 +196,15 @@ int srcfd_resampler_create(int device, const double* Ry, const double* Rx, int i
   std::vector<double> rxt((size_t)in_w * out_w);
   for (int o = 0; o < out_w; ++o)
     for (int w = 0; w < in_w; ++w) rxt[(size_t)w * out_w + o] = Rx[(size_t)o * in_w + w];
+  auto is_identity = [](const double* R, int rows, int cols) {
+    if (rows != cols) return false;
+    for (int i = 0; i < rows; ++i)
+      for (int j = 0; j < cols; ++j)
+        if (std::fabs(R[(size_t)i * cols + j] - (i == j ? 1.0 : 0.0)) > 1e-13) return false;
+    return true;
+  };
+  r->ry_identity = is_identity(Ry, out_h, in_h);
+  r->rx_identity = is_identity(Rx, out_w, in_w);
   HIPCHECK(hipMalloc(&r->d_Ry, (size_t)out_h * in_h * sizeof(double)));
   HIPCHECK(hipMalloc(&r->d_RxT, rxt.size() * sizeof(double)));
   HIPCHECK(hipMemcpy(r->d_Ry, Ry, (size_t)out_h * in_h * sizeof(double), hipMemcpyHostToDevice));

@@ -196,3 +196,24 @@ def test_handles_release_their_device_memory(srcfd, enc_weights, dec_weights):
     torch.cuda.empty_cache()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 8 << 20, f"leaked {(free0 - free1) / 2**20:.1f} MiB over 5 create/destroy cycles"
+
+
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
+def test_tail_segmentation_is_bit_identical(srcfd, enc_weights, dec_weights, kind, monkeypatch):
+    """Small batches cut every sample into 2 / 5 / 10 / 25 segments of strips handled by different workgroups (each with
+    one warm-up strip); the arithmetic per pixel is unchanged, so every segmentation must reproduce the unsegmented
+    result bit for bit -- including the de-standardise epilogue, sample seams and more virtual samples than CUs."""
+    require_gpu(srcfd)
+    rng = np.random.default_rng(77)
+    n = 13
+    x = rng.standard_normal((n, 10, 10, 1)).astype(np.float32)
+    aout = np.stack([rng.standard_normal(n) * 0.1, rng.uniform(0.05, 0.3, n)], 1).astype(np.float32)
+    m = srcfd.SRModel.from_weights(enc_weights, dec_weights, device=0)
+    m.precision = kind
+    monkeypatch.setenv("SRCFD_TAIL_SEG", "1")
+    ref = m.predict(x, out_affine=aout, nan_guard=True)
+    for seg in ("2", "5", "10", "25"):   # 13 x 25 = 325 virtual samples > 256 workgroups
+        monkeypatch.setenv("SRCFD_TAIL_SEG", seg)
+        np.testing.assert_array_equal(m.predict(x, out_affine=aout, nan_guard=True), ref, err_msg=f"segments={seg}")
+    monkeypatch.delenv("SRCFD_TAIL_SEG")
+    np.testing.assert_array_equal(m.predict(x, out_affine=aout, nan_guard=True), ref)
