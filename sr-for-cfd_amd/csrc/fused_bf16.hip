@@ -356,11 +356,19 @@ int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, cons
     const bool prof = getenv("SRCFD_TAIL_PROF") != nullptr;
     if (prof && !d_prof) HIPCHECK(hipMalloc(&d_prof, 16 * 5 * sizeof(unsigned long long)));
     tp.prof = prof ? d_prof : nullptr;
-    // small batches: cut each sample into as many segments as keep every CU at one workgroup or less
+    // Batches that do not fill the chip evenly (fewer samples than CUs, or a few more than a multiple of them): cut each
+    // sample into S segments so that the longest workgroup walks fewer strips.  Cost of a choice = strips walked by the
+    // busiest workgroup: ceil(n S / CUs) virtual samples of 50/S (+1 warm-up) strips, + 2 rounds of pipeline depth.
     int seg = 1;
     { const char* e = getenv("SRCFD_TAIL_SEG");
       if (e) seg = atoi(e);
-      else for (int cand : {2, 5, 10, 25}) if (c * cand <= fs->num_cus) seg = cand; }
+      else {
+        long best = ((long)(c + fs->num_cus - 1) / fs->num_cus) * 50 + 2;
+        for (int cand : {2, 5, 10, 25}) {
+          long cost = ((long)((long)c * cand + fs->num_cus - 1) / fs->num_cus) * (50 / cand + 1) + 2;
+          if (cost * 115 < best * 100) { best = cost; seg = cand; }  // warm-up strips and extra workgroups are not free: ask for 15 %
+        }
+      } }
     if (seg != 1 && seg != 2 && seg != 5 && seg != 10 && seg != 25) seg = 1;
     tp.seg = seg;
     const int blocks = std::min(c * seg, fs->num_cus);
