@@ -212,6 +212,10 @@ def main():
                         "traffic_source": traffic_src, "algorithmic_bytes_per_launch": n * 160000 * (2 + (4 if args.out_dtype == "f32" else 2)),
                         "avg_launch_ms": kernels[dom],
                         "algorithmic_flops_per_launch": fl,
+                        # what actually binds (not expressible as "hbm" | "mfma"): 2 240 000 swish activations per sample in this
+                        # kernel at the measured 23.6 SIMD-cycles per 64 (profiles/r01/microbench6_valu_throughput.txt), 1024 SIMDs, 2.4 GHz
+                        "valu_swish_floor_ms": round(n * 2_240_000 / 64 * 23.6 / 1024 / 2.4e9 * 1e3, 4),
+                        "frac_of_valu_swish_floor": round(n * 2_240_000 / 64 * 23.6 / 1024 / 2.4e9 * 1e3 / kernels[dom], 4),
                         "note": "swish = 2 quarter-rate transcendentals per activation: exact swish caps this network at ~0.28 of the MFMA peak on the VALU transcendental rate (DESIGN.md 4.2)"}
         else:
             fl = 2.0 * MACS_PER_SAMPLE * n
