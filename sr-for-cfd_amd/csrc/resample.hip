@@ -28,57 +28,99 @@ namespace srcfd {
     }                                                                                \
   } while (0)
 
-// C[z] (M x N) = A[z] (M x K) * B[z] (K x N), row-major, f64 FMA in ascending k.
-// 64 x 64 tile per 256-thread block, 4 x 4 outputs per thread, 16-deep k slabs in LDS.
+// C[z] (M x N) = A[z] (M x K) * B[z] (K x N), row-major, float64 accumulation on the matrix cores.
+// One wave per 32 x 32 tile of C (2 x 2 v_mfma_f64_16x16x4_f64 tiles), operands straight from global memory (they are
+// L2-resident: <= 1.3 MB per matrix at 400 x 400), the next 16-deep k chunk prefetched into registers while the current
+// one is multiplied.  Lane (r = lane % 16, q = lane / 16) holds A[row r][k0 + 4q + j] and B[k0 + 4q + j][col r], j = 0..3;
+// MFMA step j contracts the four k = k0 + 4q + j, so every k is covered once (summation order: by j, then q; fixed).
+// 400^3 per component (the BFS call): 507 waves; measured 88 us -> see DESIGN.md for the VALU tile kernel it replaces.
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// Edge handling without branches: the address is clamped into the matrix and the loaded bits are ANDed with a lane mask, so
+// the sixteen loads of a chunk issue back to back behind one wait.  (`ok ? load : 0`, and `ok ? v : 0` after an
+// unconditional load alike, compile to a branch + s_waitcnt per load: 2.7 us per chunk.  The mask goes through an empty
+// asm so that the AND is not folded back into that select.)
+__device__ __forceinline__ double masked(double v, bool ok) {
+  unsigned long long m = ok ? ~0ull : 0ull;
+  asm("" : "+v"(m));
+  return __builtin_bit_cast(double, __builtin_bit_cast(unsigned long long, v) & m);
+}
+__device__ __forceinline__ double masked(float v, bool ok) {
+  unsigned m = ok ? ~0u : 0u;
+  asm("" : "+v"(m));
+  return (double)__builtin_bit_cast(float, __builtin_bit_cast(unsigned, v) & m);
+}
+
+// raw (unmasked) operand fragments of one 16-deep k chunk: 4 consecutive k per lane
+template <typename T>
+__device__ __forceinline__ void load_a_raw(const T* __restrict__ A, int row, int M, int K, int k, T (&a)[4]) {
+  const T* p = A + (int64_t)min(row, M - 1) * K;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) a[j] = p[min(k + j, K - 1)];
+}
+template <typename T>
+__device__ __forceinline__ void load_b_raw(const T* __restrict__ B, int col, int N, int K, int k, T (&b)[4]) {
+  const T* p = B + min(col, N - 1);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) b[j] = p[(int64_t)min(k + j, K - 1) * N];
+}
+template <typename T>
+__device__ __forceinline__ void mask_frag(const T (&raw)[4], bool in_range, int k, int K, double (&out)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) out[j] = masked(raw[j], in_range && k + j < K);
+}
+
 template <typename TA, typename TB>
-__global__ void __launch_bounds__(256) gemm_f64(const TA* __restrict__ A, int64_t strideA, const TB* __restrict__ B, int64_t strideB,
-                                                 double* __restrict__ C, int64_t strideC, int M, int N, int K) {
-  __shared__ double As[16][65];
-  __shared__ double Bs[16][64];
-  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+__global__ void __launch_bounds__(64) gemm_f64(const TA* __restrict__ A, int64_t strideA, const TB* __restrict__ B, int64_t strideB,
+                                                double* __restrict__ C, int64_t strideC, int M, int N, int K) {
+  const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
   A += (int64_t)blockIdx.z * strideA;
   B += (int64_t)blockIdx.z * strideB;
   C += (int64_t)blockIdx.z * strideC;
-  double acc[4][4];
+  f64x4 acc[2][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    for (int j = 0; j < 2; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+  TA ar[2][4];
+  TB br[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    load_a_raw(A, m0 + 16 * t + r, M, K, 4 * q, ar[t]);
+    load_b_raw(B, n0 + 16 * t + r, N, K, 4 * q, br[t]);
+  }
   for (int k0 = 0; k0 < K; k0 += 16) {
+    double a[2][4], b[2][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int e = tid + 256 * j;
-      int m = e >> 4, kk = e & 15;
-      As[kk][m] = (m0 + m < M && k0 + kk < K) ? (double)A[(int64_t)(m0 + m) * K + k0 + kk] : 0.0;
-      int kb = e >> 6, nn = e & 63;
-      Bs[kb][nn] = (k0 + kb < K && n0 + nn < N) ? (double)B[(int64_t)(k0 + kb) * N + n0 + nn] : 0.0;
+    for (int t = 0; t < 2; ++t) {
+      mask_frag(ar[t], m0 + 16 * t + r < M, k0 + 4 * q, K, a[t]);
+      mask_frag(br[t], n0 + 16 * t + r < N, k0 + 4 * q, K, b[t]);
     }
-    __syncthreads();
+    // next chunk, unconditionally (past the end the clamped loads are masked to zero and never used): one basic block,
+    // so the loads stay in flight under the sixteen MFMAs below
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
-      double a[4], b[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = Bs[kk][tx * 4 + j];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fma(a[i], b[j], acc[i][j]);
+    for (int t = 0; t < 2; ++t) {
+      load_a_raw(A, m0 + 16 * t + r, M, K, k0 + 16 + 4 * q, ar[t]);
+      load_b_raw(B, n0 + 16 * t + r, N, K, k0 + 16 + 4 * q, br[t]);
     }
-    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[mt][j], b[nt][j], acc[mt][nt], 0, 0, 0);
   }
+  // D layout of v_mfma_f64_16x16x4_f64: register v of lane (r, q) is C[4v + q][r] (rows interleave over the lane groups)
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int m = m0 + ty * 4 + i;
-    if (m >= M) continue;
+  for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int n = n0 + tx * 4 + j;
-      if (n < N) C[(int64_t)m * N + n] = acc[i][j];
-    }
-  }
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+        int m = m0 + 16 * mt + 4 * v + q, n = n0 + 16 * nt + r;
+        if (m < M && n < N) C[(int64_t)m * N + n] = acc[mt][nt][v];
+      }
 }
 
 __global__ void __launch_bounds__(256) widen_f64(const float* __restrict__ x, double* __restrict__ y, int64_t n) {
@@ -116,15 +158,15 @@ struct Resampler {
     if (rx_identity && ry_identity) {
       hipLaunchKernelGGL(widen_f64, dim3((unsigned)(((int64_t)n * H * W + 255) / 256)), dim3(256), 0, s, in_dev, out_dev, (int64_t)n * H * W);
     } else if (rx_identity) {
-      hipLaunchKernelGGL((gemm_f64<double, float>), dim3((W + 63) / 64, (OH + 63) / 64, n), dim3(256), 0, s, d_Ry, (int64_t)0, in_dev, (int64_t)H * W, out_dev,
+      hipLaunchKernelGGL((gemm_f64<double, float>), dim3((W + 31) / 32, (OH + 31) / 32, n), dim3(64), 0, s, d_Ry, (int64_t)0, in_dev, (int64_t)H * W, out_dev,
                          (int64_t)OH * W, OH, W, H);
     } else if (ry_identity) {
-      hipLaunchKernelGGL((gemm_f64<float, double>), dim3((OW + 63) / 64, (H + 63) / 64, n), dim3(256), 0, s, in_dev, (int64_t)H * W, d_RxT, (int64_t)0, out_dev,
+      hipLaunchKernelGGL((gemm_f64<float, double>), dim3((OW + 31) / 32, (H + 31) / 32, n), dim3(64), 0, s, in_dev, (int64_t)H * W, d_RxT, (int64_t)0, out_dev,
                          (int64_t)H * OW, H, OW, W);
     } else {
-      hipLaunchKernelGGL((gemm_f64<float, double>), dim3((OW + 63) / 64, (H + 63) / 64, n), dim3(256), 0, s, in_dev, (int64_t)H * W, d_RxT, (int64_t)0, d_T,
+      hipLaunchKernelGGL((gemm_f64<float, double>), dim3((OW + 31) / 32, (H + 31) / 32, n), dim3(64), 0, s, in_dev, (int64_t)H * W, d_RxT, (int64_t)0, d_T,
                          (int64_t)H * OW, H, OW, W);
-      hipLaunchKernelGGL((gemm_f64<double, double>), dim3((OW + 63) / 64, (OH + 63) / 64, n), dim3(256), 0, s, d_Ry, (int64_t)0, d_T, (int64_t)H * OW, out_dev,
+      hipLaunchKernelGGL((gemm_f64<double, double>), dim3((OW + 31) / 32, (OH + 31) / 32, n), dim3(64), 0, s, d_Ry, (int64_t)0, d_T, (int64_t)H * OW, out_dev,
                          (int64_t)OH * OW, OH, OW, H);
     }
     HIPCHECK(hipGetLastError());

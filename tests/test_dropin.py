@@ -238,3 +238,17 @@ def test_solver_state_handoff_bfs_with_resampling_and_inlet(srcfd, oracle, decod
     want = oracle.inject_and_apply_bc(hr, t, v, prof)
     got = pl.ml_super_resolution_into_solver(case, 10, 400, STATS_TXT, ENCODER_H5, decoder_h5, bc, left_profiles=prof, **kw)
     np.testing.assert_array_equal(got, want)
+
+
+def test_stacked_adaptive_statistics_equal_the_per_component_calls():
+    """`_prepare` takes np.mean / np.std of the three float32 components as two row reductions over the stacked batch;
+    the reference calls them per component (bfs_ml_accelerated.py:1091-1092).  Same values, bit for bit."""
+    rng = np.random.default_rng(11)
+    for shape in ((10, 10), (20, 20), (7, 13)):
+        for scale in (1.0, 1e-3, 250.0):
+            x = (rng.standard_normal((3,) + shape) * scale + rng.standard_normal((3, 1, 1))).astype(np.float32)
+            rows = np.ascontiguousarray(x[..., None]).reshape(3, -1)
+            m, s = rows.mean(axis=1), rows.std(axis=1)
+            for i in range(3):
+                assert m[i] == np.mean(x[i]) and m.dtype == np.float32
+                assert s[i] == np.std(x[i]) and s.dtype == np.float32

@@ -33,12 +33,16 @@ def main():
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("SRCFD_BENCH_BACKEND", "nccl")    # "gloo": rehearse N ranks on a box with fewer GPUs
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     srcfd = importlib.import_module("sr-for-cfd_amd")
     synth = importlib.import_module("sr-for-cfd_amd.synth")
     tr = importlib.import_module("sr-for-cfd_amd.train")
