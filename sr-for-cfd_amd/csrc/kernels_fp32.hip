@@ -97,21 +97,22 @@ __global__ void __launch_bounds__(256) gemm_naive_f32(GemmDesc d, const float* _
 // f32 MFMA implicit GEMM.  Block = 256 threads = 4 waves; block tile 128 x
 // (32*NB); each wave owns 32 rows x NB tiles of 32 columns
 // (v_mfma_f32_32x32x2_f32: exact f32 products, k-ordered fmaf chain).
-// VEC: CI % 16 == 0, so a 16-deep K slab sits inside one (ty,tx) tap and the
-// A tile is gathered with 16-byte loads.
 // ---------------------------------------------------------------------------
-constexpr int BM = 128, BK = 16, LDA = BK + 1;
+constexpr int BM = 128;
 
-// VEC 0: scalar gather (any CI); 1: CI % 16 == 0 (a 16-deep K slab sits inside one tap);
-// 2: CI % 4 == 0 (each 16-byte group sits inside one tap).
+// VEC 0: scalar gather (any CI); 1: CI % 4 == 0 (each 16-byte group of k sits inside one tap).
+// BKT: depth of a K slab, 16 or 32.  One slab = one round trip to memory, so launches that cannot hide it behind other
+// workgroups (a single field, a training micro-batch) take the deeper slab; full-batch launches run ~1 % faster with 16.
+// The k order of the MFMA chain does not depend on it.
 // The next slab's global loads are issued into registers before the current slab's MFMAs and
 // parked in LDS after them, so HBM/L2 latency overlaps the matrix work (one LDS stage).
-template <int NB, int VEC>
+template <int NB, int VEC, int BKT>
 __global__ void __launch_bounds__(256) gemm_mfma_f32(GemmDesc d, const float* __restrict__ X,
                                                       const float* __restrict__ B,
                                                       const float* __restrict__ bias,
                                                       float* __restrict__ Y, float* __restrict__ ws, int kchunk) {
   constexpr int BN = 32 * NB;
+  constexpr int BK = BKT, LDA = BK + 1;
   __shared__ float As[BM * LDA];
   __shared__ float Bs[BK * BN];
   __shared__ int row_img[BM], row_my[BM], row_mx[BM];
@@ -137,14 +138,18 @@ __global__ void __launch_bounds__(256) gemm_mfma_f32(GemmDesc d, const float* __
   const int K = ws ? min(d.K, ((int)blockIdx.z + 1) * kchunk) : d.K;
   const int kbeg = ws ? (int)blockIdx.z * kchunk : 0;
 
-  float ra[8], rb[2 * NB];
+  constexpr int KG = BK / 4;            // 16-byte k groups per row (VEC)
+  constexpr int RJ = BM * KG / 256;     // rows per thread (VEC)
+  constexpr int AJ = BM * BK / 256;     // A elements per thread
+  constexpr int BJ = BK * BN / 256;     // B elements per thread
+  float ra[AJ], rb[BJ];
   auto fetch = [&](int k0) {
     if (VEC) {
-      const int c4 = tid & 3, k = k0 + 4 * c4;
+      const int cg = tid % KG, k = k0 + 4 * cg;
       const int tap = k / d.CI, ci0 = k - tap * d.CI, ty = tap / d.TX, tx = tap - ty * d.TX;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int row = (tid >> 2) + 64 * j;
+      for (int j = 0; j < RJ; ++j) {
+        const int row = tid / KG + (256 / KG) * j;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         const int img = row_img[row];
         if (img >= 0 && k < K) {
@@ -156,8 +161,8 @@ __global__ void __launch_bounds__(256) gemm_mfma_f32(GemmDesc d, const float* __
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        int e = tid + 256 * j, row = e >> 4, kk = e & 15, k = k0 + kk;
+      for (int j = 0; j < AJ; ++j) {
+        int e = tid + 256 * j, row = e / BK, kk = e % BK, k = k0 + kk;
         float v = 0.f;
         int img = row_img[row];
         if (img >= 0 && k < K) {
@@ -172,7 +177,7 @@ __global__ void __launch_bounds__(256) gemm_mfma_f32(GemmDesc d, const float* __
     }
     // B tile [BK][BN] (B is zero-padded to Npad columns)
 #pragma unroll
-    for (int j = 0; j < 2 * NB; ++j) {
+    for (int j = 0; j < BJ; ++j) {
       int e = tid + 256 * j, kk = e / BN, c = e - kk * BN, k = k0 + kk;
       rb[j] = (k < K) ? B[(int64_t)k * d.Npad + n0 + c] : 0.f;
     }
@@ -180,16 +185,16 @@ __global__ void __launch_bounds__(256) gemm_mfma_f32(GemmDesc d, const float* __
   auto park = [&]() {
     if (VEC) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        float* dst = As + ((tid >> 2) + 64 * j) * LDA + (tid & 3) * 4;
+      for (int j = 0; j < RJ; ++j) {
+        float* dst = As + (tid / KG + (256 / KG) * j) * LDA + (tid % KG) * 4;
         dst[0] = ra[4 * j]; dst[1] = ra[4 * j + 1]; dst[2] = ra[4 * j + 2]; dst[3] = ra[4 * j + 3];
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { int e = tid + 256 * j; As[(e >> 4) * LDA + (e & 15)] = ra[j]; }
+      for (int j = 0; j < AJ; ++j) { int e = tid + 256 * j; As[(e / BK) * LDA + (e % BK)] = ra[j]; }
     }
 #pragma unroll
-    for (int j = 0; j < 2 * NB; ++j) Bs[tid + 256 * j] = rb[j];
+    for (int j = 0; j < BJ; ++j) Bs[tid + 256 * j] = rb[j];
   };
 
   if (kbeg < K) fetch(kbeg);
@@ -229,13 +234,32 @@ __global__ void __launch_bounds__(256) gemm_mfma_f32(GemmDesc d, const float* __
     float bv = bias[n];
     int ph = n / d.CO, co = n - ph * d.CO;
     int py = ph / d.nphx, px = ph - py * d.nphx;
+    // the activation switch is taken once per tile, not once per element: with the switch inlined 16 x NB times the
+    // epilogue was 70 KB of branchy code (NB = 4) that every launch walked through instruction-cache misses
+    float v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = acc[i][r] + bv;
+    if (d.act == SRCFD_ACT_SWISH) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = act_apply_precise(v[r], SRCFD_ACT_SWISH);
+    } else if (d.act != SRCFD_ACT_LINEAR) {
+#pragma unroll 1
+      for (int r = 0; r < 16; ++r) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t = (q == r) ? v[q] : t;
+        t = act_apply(t, d.act);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) v[q] = (q == r) ? t : v[q];
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
       int img = row_img[row];
       if (img < 0) continue;
       int oy = row_my[row] * d.os + d.oy0 + py, ox = row_mx[row] * d.os + d.ox0 + px;
-      Y[(((int64_t)img * d.OH + oy) * d.OW + ox) * d.OC + co] = act_apply_precise(acc[i][r] + bv, d.act);
+      Y[(((int64_t)img * d.OH + oy) * d.OW + ox) * d.OC + co] = v[r];
     }
   }
 }
@@ -545,7 +569,7 @@ int gemm_splitk_splits(const GemmDesc& d, int* kchunk_out, bool batch_invariant)
   if (tiles >= 128 || d.K < 256 || tiles == 0) return 1;
   int want = (int)std::min<int64_t>(std::min<int64_t>((512 + tiles - 1) / tiles, d.K / 64), 256);
   if (want <= 1) return 1;
-  int kchunk = ((d.K + want - 1) / want + BK - 1) / BK * BK;
+  int kchunk = ((d.K + want - 1) / want + 31) / 32 * 32;
   if (kchunk_out) *kchunk_out = kchunk;
   return (d.K + kchunk - 1) / kchunk;
 }
@@ -596,17 +620,24 @@ hipError_t launch_gemm_mfma(const GemmDesc& d, const float* X, const float* B, c
     hipLaunchKernelGGL(conv_ci1_f32, dim3((unsigned)((d.M + 255) / 256)), dim3(256), 0, s, d, X, B, bias, Y);
     return hipGetLastError();
   }
-  const int vec = d.K <= 0 ? 0 : (d.CI % 16 == 0 ? 1 : (d.CI % 4 == 0 ? 2 : 0));
+  const int vec = (d.K > 0 && d.CI % 4 == 0) ? 1 : 0;
   int nb = (d.Npad % 128 == 0) ? 4 : ((d.Npad % 64 == 0) ? 2 : 1);
   int kchunk = d.K;
   int splits = ws ? gemm_splitk_splits(d, &kchunk, batch_invariant) : 1;
   if (splits > 1 && (size_t)splits * d.M * d.Npad > ws_floats) splits = 1;
   float* wsp = splits > 1 ? ws : nullptr;
-  dim3 grid((d.M + BM - 1) / BM, d.Npad / (32 * nb), splits);
-#define GO(NBV, VECV) hipLaunchKernelGGL((gemm_mfma_f32<NBV, VECV>), grid, dim3(256), 0, s, d, X, B, bias, Y, wsp, kchunk)
-  if (nb == 4) { if (vec == 1) GO(4, 1); else if (vec == 2) GO(4, 2); else GO(4, 0); }
-  else if (nb == 2) { if (vec == 1) GO(2, 1); else if (vec == 2) GO(2, 2); else GO(2, 0); }
-  else { if (vec == 1) GO(1, 1); else if (vec == 2) GO(1, 2); else GO(1, 0); }
+  // few rows (a solver-side call is 3 samples): narrower column blocks per wave until the launch covers the chip, and
+  // deeper K slabs.  The k order of every output element is the same for any nb / slab depth, so results stay
+  // bit-identical across batch sizes.
+  const int64_t row_tiles = (d.M + BM - 1) / BM;
+  while (nb > 1 && row_tiles * (d.Npad / (32 * nb)) * splits < 512) nb >>= 1;
+  const bool deep = row_tiles * (d.Npad / (32 * nb)) * splits < 1024;
+  dim3 grid((unsigned)row_tiles, d.Npad / (32 * nb), splits);
+#define GO2(NBV, VECV) do { if (deep) hipLaunchKernelGGL((gemm_mfma_f32<NBV, VECV, 32>), grid, dim3(256), 0, s, d, X, B, bias, Y, wsp, kchunk); \
+                            else hipLaunchKernelGGL((gemm_mfma_f32<NBV, VECV, 16>), grid, dim3(256), 0, s, d, X, B, bias, Y, wsp, kchunk); } while (0)
+#define GO(NBV) do { if (vec) GO2(NBV, 1); else GO2(NBV, 0); } while (0)
+  if (nb == 4) GO(4); else if (nb == 2) GO(2); else GO(1);
+#undef GO2
 #undef GO
   if (splits > 1) {
     int64_t total = (int64_t)d.M * d.N;
