@@ -184,10 +184,13 @@ int Model::ensure_workspace(int n) {
   size_t bytes = (size_t)chunk * max_act_elems() * sizeof(float);
   for (int i = 0; i < 2; ++i) HIPCHECK(hipMalloc(&buf[i], bytes));
   size_t need = 0;
-  for (const Op& op : ops) {
-    GemmDesc d = op.d;
-    d.M = chunk * d.MH * d.MW;
-    need = std::max(need, gemm_splitk_ws_floats(d));
+  for (size_t i = 0; i < ops.size();) {  // the ops of one layer (ConvT output phases) are launched together: their slabs coexist
+    size_t j = i;
+    GemmDesc ds[4];
+    int cnt = 0;
+    for (; j < ops.size() && ops[j].layer == ops[i].layer && cnt < 4; ++j) { ds[cnt] = ops[j].d; ds[cnt].M = chunk * ds[cnt].MH * ds[cnt].MW; ++cnt; }
+    need = std::max(need, gemm_group_ws_floats(ds, cnt));
+    i = j;
   }
   if (d_splitk) { HIPCHECK(hipFree(d_splitk)); d_splitk = nullptr; }
   splitk_floats = need;
@@ -240,6 +243,22 @@ int Model::forward_generic(const float* x_dev, int n, const float* aff_in, const
       return launch(op.name.c_str(), s, [&] {
         return launch_gemm_finalize(d, X, B, bias, y_dev, out_dtype, aff_out, flags & SRCFD_FLAG_NAN_GUARD, nonfinite, s);
       });
+    }
+    size_t j = i + 1;
+    while (j < ops.size() && ops[j].layer == op.layer && j - i < 4) ++j;
+    if (!naive && j - i > 1) {  // the output phases of one transposed convolution: one launch (kernels_fp32.hip, GemmGroup)
+      GemmDesc ds[4];
+      const float* Bs[4];
+      const float* biases[4];
+      const int cnt = (int)(j - i);
+      for (int q = 0; q < cnt; ++q) {
+        ds[q] = ops[i + q].d; ds[q].M = n * ds[q].MH * ds[q].MW;
+        Bs[q] = d_pack + ops[i + q].w_off; biases[q] = d_pack + ops[i + q].b_off;
+      }
+      rc = launch(desc.layers[op.layer].name.c_str(), s, [&] { return launch_gemm_mfma_group(ds, cnt, X, Bs, biases, Y, s, d_splitk, splitk_floats); });
+      if (rc) return rc;
+      i = j - 1;
+      continue;
     }
     rc = launch(op.name.c_str(), s, [&] { return naive ? launch_gemm_naive(d, X, B, bias, Y, s) : launch_gemm_mfma(d, X, B, bias, Y, s, d_splitk, splitk_floats); });
     if (rc) return rc;

@@ -28,6 +28,11 @@ hipError_t launch_gemm_mfma(const GemmDesc& d, const float* X, const float* B, c
 // batch_invariant (inference): the cut depends on the layer only, never on the batch size; false (training): on the tile count too.
 int gemm_splitk_splits(const GemmDesc& d, int* kchunk_out, bool batch_invariant = true);
 size_t gemm_splitk_ws_floats(const GemmDesc& d, bool batch_invariant = true);
+// The GEMMs of one layer (the output phases of a transposed convolution with kernel != stride) as one launch + one finish;
+// ws must hold gemm_group_ws_floats() floats, otherwise (or when the GEMMs do not qualify) they are launched one by one.
+hipError_t launch_gemm_mfma_group(const GemmDesc* ds, int count, const float* X, const float* const* Bs, const float* const* biases, float* Y,
+                                  hipStream_t s, float* ws, size_t ws_floats, bool batch_invariant = true);
+size_t gemm_group_ws_floats(const GemmDesc* ds, int count, bool batch_invariant = true);
 // Last layer + de-standardise + NaN guard + output cast in one kernel, for the layers gemm_fuses_finalize() accepts.
 bool gemm_fuses_finalize(const GemmDesc& d);
 hipError_t launch_gemm_finalize(const GemmDesc& d, const float* X, const float* B, const float* bias, void* out, int out_dtype,

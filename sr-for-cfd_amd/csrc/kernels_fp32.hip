@@ -107,10 +107,9 @@ constexpr int BM = 128;
 // The next slab's global loads are issued into registers before the current slab's MFMAs and
 // parked in LDS after them, so HBM/L2 latency overlaps the matrix work (one LDS stage).
 template <int NB, int VEC, int BKT>
-__global__ void __launch_bounds__(256) gemm_mfma_f32(GemmDesc d, const float* __restrict__ X,
-                                                      const float* __restrict__ B,
-                                                      const float* __restrict__ bias,
-                                                      float* __restrict__ Y, float* __restrict__ ws, int kchunk) {
+__device__ __forceinline__ void gemm_mfma_tile(const GemmDesc& d, const float* __restrict__ X, const float* __restrict__ B,
+                                               const float* __restrict__ bias, float* __restrict__ Y, float* __restrict__ ws,
+                                               int kchunk, int bx, int by, int bz) {
   constexpr int BN = 32 * NB;
   constexpr int BK = BKT, LDA = BK + 1;
   __shared__ float As[BM * LDA];
@@ -118,7 +117,7 @@ __global__ void __launch_bounds__(256) gemm_mfma_f32(GemmDesc d, const float* __
   __shared__ int row_img[BM], row_my[BM], row_mx[BM];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int m0 = bx * BM, n0 = by * BN;
 
   if (tid < BM) {
     int m = m0 + tid, img = -1, my = 0, mx = 0;
@@ -135,8 +134,8 @@ __global__ void __launch_bounds__(256) gemm_mfma_f32(GemmDesc d, const float* __
 
   // split-K (ws != nullptr): this block reduces k in [z*kchunk, (z+1)*kchunk) and leaves raw partial
   // sums in ws[z][m][n]; splitk_finish_f32 adds the slabs in z order (reproducible), bias and activation.
-  const int K = ws ? min(d.K, ((int)blockIdx.z + 1) * kchunk) : d.K;
-  const int kbeg = ws ? (int)blockIdx.z * kchunk : 0;
+  const int K = ws ? min(d.K, (bz + 1) * kchunk) : d.K;
+  const int kbeg = ws ? bz * kchunk : 0;
 
   constexpr int KG = BK / 4;            // 16-byte k groups per row (VEC)
   constexpr int RJ = BM * KG / 256;     // rows per thread (VEC)
@@ -214,7 +213,7 @@ __global__ void __launch_bounds__(256) gemm_mfma_f32(GemmDesc d, const float* __
   }
 
   if (ws) {
-    float* slab = ws + (int64_t)blockIdx.z * d.M * d.Npad;
+    float* slab = ws + (int64_t)bz * d.M * d.Npad;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       int n = n0 + 32 * i + (lane & 31);
@@ -264,13 +263,44 @@ __global__ void __launch_bounds__(256) gemm_mfma_f32(GemmDesc d, const float* __
   }
 }
 
-__global__ void __launch_bounds__(256) splitk_finish_f32(GemmDesc d, const float* __restrict__ ws, int splits,
-                                                          const float* __restrict__ bias, float* __restrict__ Y, int groups) {
+template <int NB, int VEC, int BKT>
+__global__ void __launch_bounds__(256) gemm_mfma_f32(GemmDesc d, const float* __restrict__ X, const float* __restrict__ B,
+                                                      const float* __restrict__ bias, float* __restrict__ Y, float* __restrict__ ws,
+                                                      int kchunk) {
+  gemm_mfma_tile<NB, VEC, BKT>(d, X, B, bias, Y, ws, kchunk, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// The output phases of one transposed convolution (kernel != stride: up to stride^2 GEMMs that read the same input and write
+// disjoint pixels of the same output) as ONE launch: blockIdx.z runs over (phase, K split).  A single field is a handful
+// of row tiles per phase, so four launches + their split-K finishes were four round trips of latency (~85 us of the
+// ~205 us one-field forward); results are those of the separate launches, bit for bit.
+struct GemmGroup {
+  GemmDesc d[4];
+  const float* B[4];
+  const float* bias[4];
+  float* ws[4];      // split-K slabs of the phase, or nullptr
+  int kchunk[4];
+  int zend[4];       // exclusive end of the phase's blockIdx.z range
+  int count;
+};
+
+template <int NB, int VEC, int BKT>
+__global__ void __launch_bounds__(256) gemm_mfma_group_f32(GemmGroup g, const float* __restrict__ X, float* __restrict__ Y) {
+  int p = 0;
+  while (p + 1 < g.count && (int)blockIdx.z >= g.zend[p]) ++p;
+  const int zbeg = p ? g.zend[p - 1] : 0;
+  const GemmDesc d = g.d[p];
+  if ((int)blockIdx.x * BM >= d.M) return;
+  gemm_mfma_tile<NB, VEC, BKT>(d, X, g.B[p], g.bias[p], Y, g.ws[p], g.kchunk[p], blockIdx.x, blockIdx.y, (int)blockIdx.z - zbeg);
+}
+
+__device__ __forceinline__ void splitk_finish_tile(const GemmDesc& d, const float* __restrict__ ws, int splits,
+                                                   const float* __restrict__ bias, float* __restrict__ Y, int groups, int bx) {
   // (256 / groups) outputs x `groups` slab groups per block: group g adds slabs g, g+groups, ... and the
   // groups are added in order, so the result does not depend on scheduling.
   __shared__ float red[256];
   const int epb = 256 / groups, e = threadIdx.x % epb, g = threadIdx.x / epb;
-  const int64_t idx = (int64_t)blockIdx.x * epb + e, total = (int64_t)d.M * d.N;
+  const int64_t idx = (int64_t)bx * epb + e, total = (int64_t)d.M * d.N;
   int m = 0, n = 0;
   float acc = 0.f;
   if (idx < total) {
@@ -284,6 +314,19 @@ __global__ void __launch_bounds__(256) splitk_finish_f32(GemmDesc d, const float
   int img, my, mx;
   row_decode(d, m, img, my, mx);
   Y[out_offset(d, img, my, mx, n)] = act_apply_precise(acc + bias[n], d.act);
+}
+
+__global__ void __launch_bounds__(256) splitk_finish_f32(GemmDesc d, const float* __restrict__ ws, int splits,
+                                                          const float* __restrict__ bias, float* __restrict__ Y, int groups) {
+  splitk_finish_tile(d, ws, splits, bias, Y, groups, blockIdx.x);
+}
+
+__global__ void __launch_bounds__(256) splitk_finish_group_f32(GemmGroup g, float* __restrict__ Y) {
+  const int p = blockIdx.y;
+  if (!g.ws[p]) return;  // the phase was not split: its GEMM epilogue already wrote Y
+  const GemmDesc d = g.d[p];
+  if ((int64_t)blockIdx.x * 256 >= (int64_t)d.M * d.N) return;
+  splitk_finish_tile(d, g.ws[p], g.zend[p] - (p ? g.zend[p - 1] : 0), g.bias[p], Y, 1, blockIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -644,6 +687,69 @@ hipError_t launch_gemm_mfma(const GemmDesc& d, const float* X, const float* B, c
     const int groups = (splits >= 32 && total < 65536) ? 8 : 1, epb = 256 / groups;
     hipLaunchKernelGGL(splitk_finish_f32, dim3((unsigned)((total + epb - 1) / epb)), dim3(256), 0, s, d, wsp, splits, bias, Y, groups);
   }
+  return hipGetLastError();
+}
+
+static bool uses_generic_gemm(const GemmDesc& d) {
+  if (d.M <= 0 || d.N <= 0 || d.K <= 0) return false;
+  if (is_tiled_n1_conv(d)) return false;
+  if (d.N == 1 && d.K <= 512 && d.nphx == 1) return false;
+  if (d.CI == 1 && d.N <= 8 && d.K <= 64 && d.nphx == 1 && d.CO == d.N) return false;
+  return true;
+}
+
+size_t gemm_group_ws_floats(const GemmDesc* ds, int count, bool batch_invariant) {
+  size_t total = 0;
+  for (int i = 0; i < count; ++i) total += gemm_splitk_ws_floats(ds[i], batch_invariant);
+  return total;
+}
+
+hipError_t launch_gemm_mfma_group(const GemmDesc* ds, int count, const float* X, const float* const* Bs, const float* const* biases, float* Y,
+                                  hipStream_t s, float* ws, size_t ws_floats, bool batch_invariant) {
+  bool group = count >= 2 && count <= 4;
+  for (int i = 0; group && i < count; ++i)
+    group = uses_generic_gemm(ds[i]) && ds[i].Npad == ds[0].Npad && (ds[i].CI % 4 == 0) == (ds[0].CI % 4 == 0);
+  GemmGroup g{};
+  int64_t tiles = 0, max_rows = 0, max_finish = 0;
+  size_t ws_used = 0;
+  bool any_split = false;
+  for (int i = 0; group && i < count; ++i) {
+    const GemmDesc& d = ds[i];
+    int kchunk = d.K;
+    int splits = ws ? gemm_splitk_splits(d, &kchunk, batch_invariant) : 1;
+    const size_t need = splits > 1 ? (size_t)splits * d.M * d.Npad : 0;
+    if (ws_used + need > ws_floats) { group = false; break; }
+    if (splits >= 32 && (int64_t)d.M * d.N < 65536) { group = false; break; }  // the single launch would finish in 8 groups
+    g.d[i] = d; g.B[i] = Bs[i]; g.bias[i] = biases[i];
+    g.ws[i] = splits > 1 ? ws + ws_used : nullptr;
+    g.kchunk[i] = kchunk;
+    g.zend[i] = (i ? g.zend[i - 1] : 0) + splits;
+    ws_used += need;
+    const int64_t rows = (d.M + BM - 1) / BM;
+    tiles += rows * splits;
+    max_rows = std::max(max_rows, rows);
+    if (splits > 1) { any_split = true; max_finish = std::max<int64_t>(max_finish, ((int64_t)d.M * d.N + 255) / 256); }
+  }
+  if (!group) {
+    for (int i = 0; i < count; ++i) {
+      hipError_t e = launch_gemm_mfma(ds[i], X, Bs[i], biases[i], Y, s, ws, ws_floats, batch_invariant);
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+  }
+  g.count = count;
+  const int vec = ds[0].CI % 4 == 0 ? 1 : 0, Npad = ds[0].Npad;
+  int nb = (Npad % 128 == 0) ? 4 : ((Npad % 64 == 0) ? 2 : 1);
+  while (nb > 1 && tiles * (Npad / (32 * nb)) < 512) nb >>= 1;
+  const bool deep = tiles * (Npad / (32 * nb)) < 1024;
+  dim3 grid((unsigned)max_rows, Npad / (32 * nb), g.zend[count - 1]);
+#define GO2(NBV, VECV) do { if (deep) hipLaunchKernelGGL((gemm_mfma_group_f32<NBV, VECV, 32>), grid, dim3(256), 0, s, g, X, Y); \
+                            else hipLaunchKernelGGL((gemm_mfma_group_f32<NBV, VECV, 16>), grid, dim3(256), 0, s, g, X, Y); } while (0)
+#define GO(NBV) do { if (vec) GO2(NBV, 1); else GO2(NBV, 0); } while (0)
+  if (nb == 4) GO(4); else if (nb == 2) GO(2); else GO(1);
+#undef GO2
+#undef GO
+  if (any_split) hipLaunchKernelGGL(splitk_finish_group_f32, dim3((unsigned)max_finish, count), dim3(256), 0, s, g, Y);
   return hipGetLastError();
 }
 

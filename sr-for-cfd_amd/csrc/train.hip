@@ -619,7 +619,14 @@ static int trainer_build(Trainer& t, const Model& model, int max_batch) {
   HIPCHECK(hipMalloc(&t.d_loss_partial, 1024 * sizeof(double)));
   size_t sk = 0;
   for (int b = 1; b <= max_batch; ++b) {
-    for (const TrainOp& op : t.ops) { GemmDesc d = op.fwd; d.M = b * d.MH * d.MW; sk = std::max(sk, gemm_splitk_ws_floats(d, false)); }
+    for (size_t i = 0; i < t.ops.size();) {  // the forward GEMMs of one layer are launched together: their slabs coexist
+      GemmDesc ds[4];
+      int cnt = 0;
+      size_t j = i;
+      for (; j < t.ops.size() && t.ops[j].layer == t.ops[i].layer && cnt < 4; ++j) { ds[cnt] = t.ops[j].fwd; ds[cnt].M = b * ds[cnt].MH * ds[cnt].MW; ++cnt; }
+      sk = std::max(sk, gemm_group_ws_floats(ds, cnt, false));
+      i = j;
+    }
     for (const DgradOp& op : t.dops) { GemmDesc d = op.d; d.M = b * d.MH * d.MW; sk = std::max(sk, gemm_splitk_ws_floats(d, false)); }
   }
   t.splitk_floats = sk;
@@ -636,12 +643,22 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
   hipLaunchKernelGGL(gather_pack_f32, grid(t.pack_elems), dim3(256), 0, s, params, t.d_pack_map, t.d_pack, (int64_t)t.pack_elems);
   if (t.dpack_elems) hipLaunchKernelGGL(gather_pack_f32, grid(t.dpack_elems), dim3(256), 0, s, params, t.d_dpack_map, t.d_dpack, (int64_t)t.dpack_elems);
   // 2. forward, keeping Z (pre-activation) and Y (post) of every layer
-  for (const TrainOp& op : t.ops) {
-    GemmDesc d = op.fwd;
-    d.M = n * d.MH * d.MW;
+  for (size_t i = 0; i < t.ops.size();) {
+    const TrainOp& op = t.ops[i];
+    GemmDesc ds[4];
+    const float* Bs[4];
+    const float* biases[4];
+    int cnt = 0;
+    size_t j = i;
+    for (; j < t.ops.size() && t.ops[j].layer == op.layer && cnt < 4; ++j) {  // ConvT output phases: one launch
+      ds[cnt] = t.ops[j].fwd; ds[cnt].M = n * ds[cnt].MH * ds[cnt].MW;
+      Bs[cnt] = t.d_pack + t.ops[j].w_off; biases[cnt] = t.d_pack + t.ops[j].b_off;
+      ++cnt;
+    }
     const float* X = op.layer == 0 ? x : t.Y[op.layer - 1];
-    HIPCHECK(launch_gemm_mfma(d, X, t.d_pack + op.w_off, t.d_pack + op.b_off, t.Z[op.layer], s, t.d_splitk, t.splitk_floats, false));
-    const bool last_of_layer = (&op == &t.ops.back()) || ((&op + 1)->layer != op.layer);
+    HIPCHECK(launch_gemm_mfma_group(ds, cnt, X, Bs, biases, t.Z[op.layer], s, t.d_splitk, t.splitk_floats, false));
+    i = j;
+    const bool last_of_layer = i == t.ops.size() || t.ops[i].layer != op.layer;
     if (last_of_layer && t.layers[op.layer].swish) {
       int64_t e = (int64_t)n * t.layers[op.layer].out_elems;
       hipLaunchKernelGGL(swish_fwd_f32, grid(e), dim3(256), 0, s, t.Z[op.layer], t.Y[op.layer], e);
