@@ -267,7 +267,7 @@ int srcfd_resample_device(srcfd_resampler* r, const float* in_dev, int n, double
 
 int srcfd_predict_resampled(srcfd_model* m, srcfd_resampler* r, const float* x, int n, const float* in_affine, const float* out_affine, double* y,
                             int flags, int64_t* n_nonfinite) {
-  if (!m || !r) { set_error("srcfd_predict_resampled: bad arguments"); return SRCFD_EINVAL; }
+  if (!m || !r || n < 0 || (n > 0 && (!x || !y))) { set_error("srcfd_predict_resampled: bad arguments"); return SRCFD_EINVAL; }
   srcfd::Model* mm = reinterpret_cast<srcfd::Model*>(m);
   Resampler* rr = reinterpret_cast<Resampler*>(r);
   const int* os = mm->desc.out_shape();

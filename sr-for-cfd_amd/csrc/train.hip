@@ -443,7 +443,25 @@ struct Trainer {
   float* d_dpack = nullptr; int* d_dpack_map = nullptr; size_t dpack_elems = 0;
   float* d_zero_bias = nullptr; size_t zero_bias_elems = 0;
   std::vector<float*> Z, Y;       // per compute layer (Y aliases Z for linear layers)
-  float* dbuf[2] = {nullptr, nullptr};
+  float* dbuf[3] = {nullptr, nullptr, nullptr};   // ring: dZ of layer li, li-1, li-2
+  // The weight gradients of a layer (wgrad + finish) depend only on its dZ and on the forward activations, not on the
+  // data-gradient chain, so they run on a second stream beside it (at micro-batch sizes no kernel fills the chip).
+  hipStream_t aux = nullptr;
+  std::vector<hipEvent_t> ev_dz, ev_wg;            // per layer: dZ ready (main stream) / weight gradient done (aux)
+  bool overlap = true;                             // SRCFD_TRAIN_OVERLAP=0: everything on the caller's stream
+  // A step is ~100 launches and event operations of 5-40 us kernels: issued one by one the host cannot keep the device
+  // fed (20 % of the step was idle gaps).  The second time a step with the same buffers and batch size is asked for it is
+  // captured (both streams: the aux branch forks and joins inside the capture) and replayed as one hipGraph launch.
+  // x and y go through staging buffers so that the graph's pointers never change.
+  struct StepKey {
+    const float* params = nullptr; float* grads = nullptr; double* sse = nullptr; int n = 0; float loss_scale = 0.f;
+    bool operator==(const StepKey& o) const { return params == o.params && grads == o.grads && sse == o.sse && n == o.n && loss_scale == o.loss_scale; }
+  };
+  struct StepGraph { StepKey key; int seen = 0; hipGraphExec_t exec = nullptr; };
+  std::vector<StepGraph> graphs;                   // at most 8 keys (full batches, the ragged last batch, ...)
+  bool use_graph = true;                           // SRCFD_TRAIN_GRAPH=0: plain launches
+  hipStream_t cap_stream = nullptr;
+  float* d_xs = nullptr; float* d_ys = nullptr; size_t x_elems = 0, y_elems = 0;   // per-sample sizes of the staging buffers
   float* d_part = nullptr; size_t part_elems = 0;
   float* d_splitk = nullptr; size_t splitk_floats = 0;
   double* d_loss_partial = nullptr;
@@ -452,8 +470,15 @@ struct Trainer {
 
 Trainer::~Trainer() {
   (void)hipSetDevice(device);
+  for (auto& g : graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
+  if (cap_stream) (void)hipStreamDestroy(cap_stream);
+  if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); }
+  if (d_xs) (void)hipFree(d_xs);
+  if (d_ys) (void)hipFree(d_ys);
+  for (hipEvent_t e : ev_dz) (void)hipEventDestroy(e);
+  for (hipEvent_t e : ev_wg) (void)hipEventDestroy(e);
   for (void* p : {(void*)d_pack, (void*)d_pack_map, (void*)d_dpack, (void*)d_dpack_map, (void*)d_zero_bias, (void*)dbuf[0], (void*)dbuf[1],
-                  (void*)d_part, (void*)d_loss_partial, (void*)d_splitk})
+                  (void*)dbuf[2], (void*)d_part, (void*)d_loss_partial, (void*)d_splitk})
     if (p) (void)hipFree(p);
   for (size_t i = 0; i < Z.size(); ++i) {
     if (Y[i] && Y[i] != Z[i]) (void)hipFree(Y[i]);
@@ -616,6 +641,24 @@ static int trainer_build(Trainer& t, const Model& model, int max_batch) {
     t.Y.push_back(y);
   }
   for (auto*& b : t.dbuf) HIPCHECK(hipMalloc(&b, (size_t)max_batch * maxe * sizeof(float)));
+  { const char* e = getenv("SRCFD_TRAIN_OVERLAP"); t.overlap = !(e && atoi(e) == 0); }
+  { const char* e = getenv("SRCFD_TRAIN_GRAPH"); t.use_graph = !(e && atoi(e) == 0); }
+  if (t.use_graph) {
+    t.x_elems = t.layers.front().in_elems; t.y_elems = t.layers.back().out_elems;
+    HIPCHECK(hipMalloc(&t.d_xs, (size_t)max_batch * t.x_elems * sizeof(float)));
+    HIPCHECK(hipMalloc(&t.d_ys, (size_t)max_batch * t.y_elems * sizeof(float)));
+    HIPCHECK(hipStreamCreateWithFlags(&t.cap_stream, hipStreamNonBlocking));
+  }
+  if (t.overlap) {
+    HIPCHECK(hipStreamCreateWithFlags(&t.aux, hipStreamNonBlocking));
+    for (size_t i = 0; i < t.layers.size(); ++i) {
+      hipEvent_t a, b;
+      HIPCHECK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+      t.ev_dz.push_back(a);
+      HIPCHECK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+      t.ev_wg.push_back(b);
+    }
+  }
   HIPCHECK(hipMalloc(&t.d_loss_partial, 1024 * sizeof(double)));
   size_t sk = 0;
   for (int b = 1; b <= max_batch; ++b) {
@@ -670,12 +713,19 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
   int nb = (int)std::min<int64_t>(1024, (oe + 255) / 256);
   hipLaunchKernelGGL(mse_grad_f32, dim3(nb), dim3(256), 0, s, t.Y[L - 1], y, t.dbuf[0], oe, loss_scale, t.d_loss_partial);
   if (sse_dev) hipLaunchKernelGGL(sum_partials_f64, dim3(1), dim3(256), 0, s, t.d_loss_partial, nb, sse_dev);
-  // 4. backward
+  // 4. backward.  Main stream: swish' -> data gradient -> swish' -> ... (the dependent chain); aux stream: the weight
+  //    gradients, each waiting only for its layer's dZ.  dZ buffers rotate through a ring of three, so the data-gradient
+  //    chain may run two layers ahead of the weight gradients before it has to wait for one of them.
   int cur = 0;
+  hipStream_t ws = t.overlap ? t.aux : s;
   for (int li = L - 1; li >= 0; --li) {
     float* dZ = t.dbuf[cur];
     int64_t e = (int64_t)n * t.layers[li].out_elems;
     if (t.layers[li].swish) hipLaunchKernelGGL(swish_bwd_f32, grid(e), dim3(256), 0, s, t.Z[li], dZ, e);
+    if (t.overlap) {
+      HIPCHECK(hipEventRecord(t.ev_dz[li], s));
+      HIPCHECK(hipStreamWaitEvent(t.aux, t.ev_dz[li], 0));
+    }
     const float* X = li == 0 ? x : t.Y[li - 1];
     for (const TrainOp& op : t.ops) {
       if (op.layer != li) continue;
@@ -684,19 +734,24 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
       const WgradPlan wp = wgrad_plan(d);
       const int64_t elems = (int64_t)(d.K + 1) * d.Npad;
       if ((size_t)wp.nslices * elems > t.part_elems) { set_error("training: gradient slab buffer too small"); return SRCFD_EINVAL; }
-      launch_wgrad(d, wp, X, dZ, t.d_part, s);
+      launch_wgrad(d, wp, X, dZ, t.d_part, ws);
       const int groups = wp.nslices >= 256 ? 32 : (wp.nslices >= 64 ? 8 : (wp.nslices >= 8 ? 4 : 1)), epb = 256 / groups;
-      hipLaunchKernelGGL(wgrad_finish_f32, dim3((unsigned)((elems + epb - 1) / epb)), dim3(256), 0, s, t.d_part, wp.nslices, elems, op.d_gmap, grads,
+      hipLaunchKernelGGL(wgrad_finish_f32, dim3((unsigned)((elems + epb - 1) / epb)), dim3(256), 0, ws, t.d_part, wp.nslices, elems, op.d_gmap, grads,
                          d.K, d.N, d.Npad, d.CO, groups);
     }
+    if (t.overlap) HIPCHECK(hipEventRecord(t.ev_wg[li], t.aux));
     if (li > 0) {
       const DgradOp& dg = t.dops[li - 1];
       GemmDesc d = dg.d;
       d.M = n * d.MH * d.MW;
-      HIPCHECK(launch_gemm_mfma(d, dZ, t.d_dpack + dg.w_off, t.d_zero_bias, t.dbuf[cur ^ 1], s, t.d_splitk, t.splitk_floats, false));
-      cur ^= 1;
+      const int nxt = (cur + 1) % 3;
+      // the ring slot about to be overwritten held dZ of layer li+2: its weight gradient must have read it
+      if (t.overlap && li + 2 <= L - 1) HIPCHECK(hipStreamWaitEvent(s, t.ev_wg[li + 2], 0));
+      HIPCHECK(launch_gemm_mfma(d, dZ, t.d_dpack + dg.w_off, t.d_zero_bias, t.dbuf[nxt], s, t.d_splitk, t.splitk_floats, false));
+      cur = nxt;
     }
   }
+  if (t.overlap) HIPCHECK(hipStreamWaitEvent(s, t.ev_wg[0], 0));  // aux is in order: layer 0's event covers all of them
   HIPCHECK(hipGetLastError());
   return SRCFD_OK;
 }
@@ -739,8 +794,33 @@ int srcfd_trainer_get_params(const srcfd_trainer* t, float* params_host) {
 int srcfd_trainer_forward_backward(srcfd_trainer* t, const float* params_dev, const float* x_dev, const float* y_dev, int n, float loss_scale,
                                    float* grads_dev, double* sse_dev, void* hip_stream) {
   if (!t || !params_dev || !x_dev || !y_dev || !grads_dev) { set_error("bad arguments"); return SRCFD_EINVAL; }
-  return srcfd::trainer_step(*reinterpret_cast<Trainer*>(t), params_dev, x_dev, y_dev, n, loss_scale, grads_dev, sse_dev,
-                             reinterpret_cast<hipStream_t>(hip_stream));
+  Trainer& tt = *reinterpret_cast<Trainer*>(t);
+  hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+  if (!tt.use_graph || n <= 0 || n > tt.max_batch) return srcfd::trainer_step(tt, params_dev, x_dev, y_dev, n, loss_scale, grads_dev, sse_dev, s);
+  HIPCHECK(hipSetDevice(tt.device));
+  HIPCHECK(hipMemcpyAsync(tt.d_xs, x_dev, (size_t)n * tt.x_elems * sizeof(float), hipMemcpyDeviceToDevice, s));
+  HIPCHECK(hipMemcpyAsync(tt.d_ys, y_dev, (size_t)n * tt.y_elems * sizeof(float), hipMemcpyDeviceToDevice, s));
+  Trainer::StepKey key;
+  key.params = params_dev; key.grads = grads_dev; key.sse = sse_dev; key.n = n; key.loss_scale = loss_scale;
+  Trainer::StepGraph* slot = nullptr;
+  for (auto& g : tt.graphs) if (g.key == key) slot = &g;
+  if (!slot && tt.graphs.size() < 8) { tt.graphs.emplace_back(); slot = &tt.graphs.back(); slot->key = key; }
+  if (slot && slot->exec) { HIPCHECK(hipGraphLaunch(slot->exec, s)); return SRCFD_OK; }
+  if (slot && ++slot->seen == 2) {  // every one-time set-up (function attributes, ...) happened on the first, plain pass
+    HIPCHECK(hipStreamBeginCapture(tt.cap_stream, hipStreamCaptureModeThreadLocal));
+    int rc = srcfd::trainer_step(tt, params_dev, tt.d_xs, tt.d_ys, n, loss_scale, grads_dev, sse_dev, tt.cap_stream);
+    hipGraph_t g = nullptr;
+    hipError_t e = hipStreamEndCapture(tt.cap_stream, &g);
+    if (rc == SRCFD_OK && e == hipSuccess && g) {
+      e = hipGraphInstantiate(&slot->exec, g, nullptr, nullptr, 0);
+      (void)hipGraphDestroy(g);
+      if (e == hipSuccess) { HIPCHECK(hipGraphLaunch(slot->exec, s)); return SRCFD_OK; }
+      slot->exec = nullptr;
+    } else if (g) (void)hipGraphDestroy(g);
+    (void)hipGetLastError();  // capture not possible here: plain launches from now on for this key
+    slot->seen = 3;
+  }
+  return srcfd::trainer_step(tt, params_dev, tt.d_xs, tt.d_ys, n, loss_scale, grads_dev, sse_dev, s);
 }
 
 int srcfd_adam_step(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, int64_t n, int step, float lr, float beta1,

@@ -9,4 +9,4 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/$TAG -o $TAG -- pyt
 F=$(find $OUT/$TAG -name "*kernel_stats.csv" | sort | tail -1)
 if [ -n "$F" ]; then cp $F $OUT/${TAG}_kernel_stats.csv; fi
 T=$(find $OUT/$TAG -name "*kernel_trace.csv" | sort | tail -1)
-if [ -n "$T" ]; then python3 $R/tools/trace_by_grid.py $T > $OUT/${TAG}_by_grid.txt; rm -f $T; fi
+if [ -n "$T" ]; then python3 $R/tools/trace_by_grid.py $T > $OUT/${TAG}_by_grid.txt; python3 $R/tools/trace_overlap.py $T 300 > $OUT/${TAG}_overlap.txt; rm -f $T; fi
