@@ -21,17 +21,28 @@ struct GemmDesc {
   int act;
 };
 
+// Training epilogues of the GEMM (train.hip): the element-wise pass that would follow the launch, done on the accumulators.
+//   mode 1 (forward):        Y = v (pre-activation, kept for the backward pass),  y2 = swish(v)
+//   mode 2 (data gradient):  Y = v * swish'(zaux)   (zaux: the pre-activation stored at the same offsets)
+// Same expressions as the stand-alone swish_fwd_f32 / swish_bwd_f32 kernels, so fused and unfused results are identical.
+struct EpiAux {
+  float* y2 = nullptr;
+  const float* zaux = nullptr;
+  int mode = 0;
+};
+bool gemm_supports_epi_aux(const GemmDesc& d);
+
 hipError_t launch_gemm_naive(const GemmDesc& d, const float* X, const float* B, const float* bias, float* Y, hipStream_t s);
 // ws: optional split-K scratch (gemm_splitk_ws_floats(d) floats); without it the launch never splits.
 hipError_t launch_gemm_mfma(const GemmDesc& d, const float* X, const float* B, const float* bias, float* Y, hipStream_t s,
-                            float* ws = nullptr, size_t ws_floats = 0, bool batch_invariant = true);
+                            float* ws = nullptr, size_t ws_floats = 0, bool batch_invariant = true, EpiAux aux = EpiAux());
 // batch_invariant (inference): the cut depends on the layer only, never on the batch size; false (training): on the tile count too.
 int gemm_splitk_splits(const GemmDesc& d, int* kchunk_out, bool batch_invariant = true);
 size_t gemm_splitk_ws_floats(const GemmDesc& d, bool batch_invariant = true);
 // The GEMMs of one layer (the output phases of a transposed convolution with kernel != stride) as one launch + one finish;
 // ws must hold gemm_group_ws_floats() floats, otherwise (or when the GEMMs do not qualify) they are launched one by one.
 hipError_t launch_gemm_mfma_group(const GemmDesc* ds, int count, const float* X, const float* const* Bs, const float* const* biases, float* Y,
-                                  hipStream_t s, float* ws, size_t ws_floats, bool batch_invariant = true);
+                                  hipStream_t s, float* ws, size_t ws_floats, bool batch_invariant = true, EpiAux aux = EpiAux());
 size_t gemm_group_ws_floats(const GemmDesc* ds, int count, bool batch_invariant = true);
 // Last layer + de-standardise + NaN guard + output cast in one kernel, for the layers gemm_fuses_finalize() accepts.
 bool gemm_fuses_finalize(const GemmDesc& d);

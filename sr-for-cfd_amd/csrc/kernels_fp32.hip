@@ -49,6 +49,13 @@ __device__ __forceinline__ float act_apply_precise(float v, int act) {
   return act_apply(v, act);
 }
 
+// training epilogues (EpiAux): the expressions of train.hip's swish_fwd_f32 / swish_bwd_f32
+__device__ __forceinline__ float swish_train(float v) { return v / (1.0f + expf(-v)); }
+__device__ __forceinline__ float swish_grad_train(float z) {
+  float s = 1.0f / (1.0f + expf(-z));
+  return s + z * s * (1.0f - s);
+}
+
 __device__ __forceinline__ void row_decode(const GemmDesc& d, int m, int& img, int& my, int& mx) {
   int per = d.MH * d.MW;
   img = m / per;
@@ -109,7 +116,7 @@ constexpr int BM = 128;
 template <int NB, int VEC, int BKT>
 __device__ __forceinline__ void gemm_mfma_tile(const GemmDesc& d, const float* __restrict__ X, const float* __restrict__ B,
                                                const float* __restrict__ bias, float* __restrict__ Y, float* __restrict__ ws,
-                                               int kchunk, int bx, int by, int bz) {
+                                               int kchunk, int bx, int by, int bz, const EpiAux& aux) {
   constexpr int BN = 32 * NB;
   constexpr int BK = BKT, LDA = BK + 1;
   __shared__ float As[BM * LDA];
@@ -238,6 +245,20 @@ __device__ __forceinline__ void gemm_mfma_tile(const GemmDesc& d, const float* _
     float v[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = acc[i][r] + bv;
+    if (aux.mode) {  // training: the element-wise pass that would follow this launch (kernels.h, EpiAux)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        int row = wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        int img = row_img[row];
+        if (img < 0) continue;
+        const float t = v[r];
+        int oy = row_my[row] * d.os + d.oy0 + py, ox = row_mx[row] * d.os + d.ox0 + px;
+        const int64_t off = (((int64_t)img * d.OH + oy) * d.OW + ox) * d.OC + co;
+        if (aux.mode == 1) { Y[off] = t; aux.y2[off] = swish_train(t); }
+        else Y[off] = t * swish_grad_train(aux.zaux[off]);
+      }
+      continue;
+    }
     if (d.act == SRCFD_ACT_SWISH) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = act_apply_precise(v[r], SRCFD_ACT_SWISH);
@@ -266,8 +287,8 @@ __device__ __forceinline__ void gemm_mfma_tile(const GemmDesc& d, const float* _
 template <int NB, int VEC, int BKT>
 __global__ void __launch_bounds__(256) gemm_mfma_f32(GemmDesc d, const float* __restrict__ X, const float* __restrict__ B,
                                                       const float* __restrict__ bias, float* __restrict__ Y, float* __restrict__ ws,
-                                                      int kchunk) {
-  gemm_mfma_tile<NB, VEC, BKT>(d, X, B, bias, Y, ws, kchunk, blockIdx.x, blockIdx.y, blockIdx.z);
+                                                      int kchunk, EpiAux aux) {
+  gemm_mfma_tile<NB, VEC, BKT>(d, X, B, bias, Y, ws, kchunk, blockIdx.x, blockIdx.y, blockIdx.z, aux);
 }
 
 // The output phases of one transposed convolution (kernel != stride: up to stride^2 GEMMs that read the same input and write
@@ -285,17 +306,18 @@ struct GemmGroup {
 };
 
 template <int NB, int VEC, int BKT>
-__global__ void __launch_bounds__(256) gemm_mfma_group_f32(GemmGroup g, const float* __restrict__ X, float* __restrict__ Y) {
+__global__ void __launch_bounds__(256) gemm_mfma_group_f32(GemmGroup g, const float* __restrict__ X, float* __restrict__ Y, EpiAux aux) {
   int p = 0;
   while (p + 1 < g.count && (int)blockIdx.z >= g.zend[p]) ++p;
   const int zbeg = p ? g.zend[p - 1] : 0;
   const GemmDesc d = g.d[p];
   if ((int)blockIdx.x * BM >= d.M) return;
-  gemm_mfma_tile<NB, VEC, BKT>(d, X, g.B[p], g.bias[p], Y, g.ws[p], g.kchunk[p], blockIdx.x, blockIdx.y, (int)blockIdx.z - zbeg);
+  gemm_mfma_tile<NB, VEC, BKT>(d, X, g.B[p], g.bias[p], Y, g.ws[p], g.kchunk[p], blockIdx.x, blockIdx.y, (int)blockIdx.z - zbeg, aux);
 }
 
 __device__ __forceinline__ void splitk_finish_tile(const GemmDesc& d, const float* __restrict__ ws, int splits,
-                                                   const float* __restrict__ bias, float* __restrict__ Y, int groups, int bx) {
+                                                   const float* __restrict__ bias, float* __restrict__ Y, int groups, int bx,
+                                                   const EpiAux& aux) {
   // (256 / groups) outputs x `groups` slab groups per block: group g adds slabs g, g+groups, ... and the
   // groups are added in order, so the result does not depend on scheduling.
   __shared__ float red[256];
@@ -313,20 +335,24 @@ __device__ __forceinline__ void splitk_finish_tile(const GemmDesc& d, const floa
   for (int q = 1; q < groups; ++q) acc += red[q * epb + e];
   int img, my, mx;
   row_decode(d, m, img, my, mx);
-  Y[out_offset(d, img, my, mx, n)] = act_apply_precise(acc + bias[n], d.act);
+  const int64_t off = out_offset(d, img, my, mx, n);
+  const float v = acc + bias[n];
+  if (aux.mode == 1) { Y[off] = v; aux.y2[off] = swish_train(v); }
+  else if (aux.mode == 2) Y[off] = v * swish_grad_train(aux.zaux[off]);
+  else Y[off] = act_apply_precise(v, d.act);
 }
 
 __global__ void __launch_bounds__(256) splitk_finish_f32(GemmDesc d, const float* __restrict__ ws, int splits,
-                                                          const float* __restrict__ bias, float* __restrict__ Y, int groups) {
-  splitk_finish_tile(d, ws, splits, bias, Y, groups, blockIdx.x);
+                                                          const float* __restrict__ bias, float* __restrict__ Y, int groups, EpiAux aux) {
+  splitk_finish_tile(d, ws, splits, bias, Y, groups, blockIdx.x, aux);
 }
 
-__global__ void __launch_bounds__(256) splitk_finish_group_f32(GemmGroup g, float* __restrict__ Y) {
+__global__ void __launch_bounds__(256) splitk_finish_group_f32(GemmGroup g, float* __restrict__ Y, EpiAux aux) {
   const int p = blockIdx.y;
   if (!g.ws[p]) return;  // the phase was not split: its GEMM epilogue already wrote Y
   const GemmDesc d = g.d[p];
   if ((int64_t)blockIdx.x * 256 >= (int64_t)d.M * d.N) return;
-  splitk_finish_tile(d, g.ws[p], g.zend[p] - (p ? g.zend[p - 1] : 0), g.bias[p], Y, 1, blockIdx.x);
+  splitk_finish_tile(d, g.ws[p], g.zend[p] - (p ? g.zend[p - 1] : 0), g.bias[p], Y, 1, blockIdx.x, aux);
 }
 
 // ---------------------------------------------------------------------------
@@ -490,7 +516,7 @@ __global__ void __launch_bounds__(256) conv_n1_tile_f32(GemmDesc d, const float*
 // single-input-channel conv with <= 8 output channels (the data gradient of `output_image_400`:
 // a 3x3 1->8 flipped-tap conv over 400x400): one thread per pixel, 8 accumulators, two 16-byte stores.
 __global__ void __launch_bounds__(256) conv_ci1_f32(GemmDesc d, const float* __restrict__ X, const float* __restrict__ B,
-                                                     const float* __restrict__ bias, float* __restrict__ Y) {
+                                                     const float* __restrict__ bias, float* __restrict__ Y, EpiAux aux) {
   __shared__ float w[64 * 8];
   for (int i = threadIdx.x; i < d.K * 8; i += 256) { int k = i >> 3, c = i & 7; w[i] = c < d.N ? B[(int64_t)k * d.Npad + c] : 0.f; }
   __syncthreads();
@@ -514,7 +540,17 @@ __global__ void __launch_bounds__(256) conv_ci1_f32(GemmDesc d, const float* __r
       for (int c = 0; c < 8; ++c) acc[c] = fmaf(v, wp[c], acc[c]);
     }
   }
-  float* yp = Y + out_offset(d, img, my, mx, 0);
+  const int64_t off0 = out_offset(d, img, my, mx, 0);
+  float* yp = Y + off0;
+  if (aux.mode) {  // training epilogues (kernels.h, EpiAux); channels of one pixel are contiguous
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      if (c >= d.N) continue;
+      if (aux.mode == 1) { yp[c] = acc[c]; aux.y2[off0 + c] = swish_train(acc[c]); }
+      else yp[c] = acc[c] * swish_grad_train(aux.zaux[off0 + c]);
+    }
+    return;
+  }
   if (d.N == 8 && (d.OC & 3) == 0) {
     reinterpret_cast<float4*>(yp)[0] = make_float4(act_apply_precise(acc[0], d.act), act_apply_precise(acc[1], d.act),
                                                     act_apply_precise(acc[2], d.act), act_apply_precise(acc[3], d.act));
@@ -642,9 +678,12 @@ hipError_t launch_gemm_finalize(const GemmDesc& d, const float* X, const float* 
   return hipGetLastError();
 }
 
+static bool is_ci1_conv(const GemmDesc& d) { return d.CI == 1 && d.N <= 8 && d.K <= 64 && d.nphx == 1 && d.CO == d.N; }
+
 hipError_t launch_gemm_mfma(const GemmDesc& d, const float* X, const float* B, const float* bias, float* Y, hipStream_t s, float* ws,
-                            size_t ws_floats, bool batch_invariant) {
+                            size_t ws_floats, bool batch_invariant, EpiAux aux) {
   if (d.M == 0 || d.N == 0) return hipSuccess;
+  if (aux.mode && !gemm_supports_epi_aux(d)) return hipErrorInvalidValue;
   if (is_tiled_n1_conv(d)) {
     dim3 grid((d.OW + CT_W - 1) / CT_W, (d.OH + CT_H - 1) / CT_H, d.M / (d.MH * d.MW));
     hipLaunchKernelGGL(conv_n1_tile_f32<0>, grid, dim3(256), 0, s, d, X, B, bias, Y, FinalEpilogue{});
@@ -660,7 +699,7 @@ hipError_t launch_gemm_mfma(const GemmDesc& d, const float* X, const float* B, c
     return hipGetLastError();
   }
   if (d.CI == 1 && d.N <= 8 && d.K <= 64 && d.nphx == 1 && d.CO == d.N) {
-    hipLaunchKernelGGL(conv_ci1_f32, dim3((unsigned)((d.M + 255) / 256)), dim3(256), 0, s, d, X, B, bias, Y);
+    hipLaunchKernelGGL(conv_ci1_f32, dim3((unsigned)((d.M + 255) / 256)), dim3(256), 0, s, d, X, B, bias, Y, aux);
     return hipGetLastError();
   }
   const int vec = (d.K > 0 && d.CI % 4 == 0) ? 1 : 0;
@@ -676,8 +715,8 @@ hipError_t launch_gemm_mfma(const GemmDesc& d, const float* X, const float* B, c
   while (nb > 1 && row_tiles * (d.Npad / (32 * nb)) * splits < 512) nb >>= 1;
   const bool deep = row_tiles * (d.Npad / (32 * nb)) * splits < 1024;
   dim3 grid((unsigned)row_tiles, d.Npad / (32 * nb), splits);
-#define GO2(NBV, VECV) do { if (deep) hipLaunchKernelGGL((gemm_mfma_f32<NBV, VECV, 32>), grid, dim3(256), 0, s, d, X, B, bias, Y, wsp, kchunk); \
-                            else hipLaunchKernelGGL((gemm_mfma_f32<NBV, VECV, 16>), grid, dim3(256), 0, s, d, X, B, bias, Y, wsp, kchunk); } while (0)
+#define GO2(NBV, VECV) do { if (deep) hipLaunchKernelGGL((gemm_mfma_f32<NBV, VECV, 32>), grid, dim3(256), 0, s, d, X, B, bias, Y, wsp, kchunk, aux); \
+                            else hipLaunchKernelGGL((gemm_mfma_f32<NBV, VECV, 16>), grid, dim3(256), 0, s, d, X, B, bias, Y, wsp, kchunk, aux); } while (0)
 #define GO(NBV) do { if (vec) GO2(NBV, 1); else GO2(NBV, 0); } while (0)
   if (nb == 4) GO(4); else if (nb == 2) GO(2); else GO(1);
 #undef GO2
@@ -685,7 +724,7 @@ hipError_t launch_gemm_mfma(const GemmDesc& d, const float* X, const float* B, c
   if (splits > 1) {
     int64_t total = (int64_t)d.M * d.N;
     const int groups = (splits >= 32 && total < 65536) ? 8 : 1, epb = 256 / groups;
-    hipLaunchKernelGGL(splitk_finish_f32, dim3((unsigned)((total + epb - 1) / epb)), dim3(256), 0, s, d, wsp, splits, bias, Y, groups);
+    hipLaunchKernelGGL(splitk_finish_f32, dim3((unsigned)((total + epb - 1) / epb)), dim3(256), 0, s, d, wsp, splits, bias, Y, groups, aux);
   }
   return hipGetLastError();
 }
@@ -704,8 +743,10 @@ size_t gemm_group_ws_floats(const GemmDesc* ds, int count, bool batch_invariant)
   return total;
 }
 
+bool gemm_supports_epi_aux(const GemmDesc& d) { return uses_generic_gemm(d) || (is_ci1_conv(d) && d.M > 0 && d.K > 0); }
+
 hipError_t launch_gemm_mfma_group(const GemmDesc* ds, int count, const float* X, const float* const* Bs, const float* const* biases, float* Y,
-                                  hipStream_t s, float* ws, size_t ws_floats, bool batch_invariant) {
+                                  hipStream_t s, float* ws, size_t ws_floats, bool batch_invariant, EpiAux aux) {
   bool group = count >= 2 && count <= 4;
   for (int i = 0; group && i < count; ++i)
     group = uses_generic_gemm(ds[i]) && ds[i].Npad == ds[0].Npad && (ds[i].CI % 4 == 0) == (ds[0].CI % 4 == 0);
@@ -732,7 +773,7 @@ hipError_t launch_gemm_mfma_group(const GemmDesc* ds, int count, const float* X,
   }
   if (!group) {
     for (int i = 0; i < count; ++i) {
-      hipError_t e = launch_gemm_mfma(ds[i], X, Bs[i], biases[i], Y, s, ws, ws_floats, batch_invariant);
+      hipError_t e = launch_gemm_mfma(ds[i], X, Bs[i], biases[i], Y, s, ws, ws_floats, batch_invariant, aux);
       if (e != hipSuccess) return e;
     }
     return hipSuccess;
@@ -743,13 +784,13 @@ hipError_t launch_gemm_mfma_group(const GemmDesc* ds, int count, const float* X,
   while (nb > 1 && tiles * (Npad / (32 * nb)) < 512) nb >>= 1;
   const bool deep = tiles * (Npad / (32 * nb)) < 1024;
   dim3 grid((unsigned)max_rows, Npad / (32 * nb), g.zend[count - 1]);
-#define GO2(NBV, VECV) do { if (deep) hipLaunchKernelGGL((gemm_mfma_group_f32<NBV, VECV, 32>), grid, dim3(256), 0, s, g, X, Y); \
-                            else hipLaunchKernelGGL((gemm_mfma_group_f32<NBV, VECV, 16>), grid, dim3(256), 0, s, g, X, Y); } while (0)
+#define GO2(NBV, VECV) do { if (deep) hipLaunchKernelGGL((gemm_mfma_group_f32<NBV, VECV, 32>), grid, dim3(256), 0, s, g, X, Y, aux); \
+                            else hipLaunchKernelGGL((gemm_mfma_group_f32<NBV, VECV, 16>), grid, dim3(256), 0, s, g, X, Y, aux); } while (0)
 #define GO(NBV) do { if (vec) GO2(NBV, 1); else GO2(NBV, 0); } while (0)
   if (nb == 4) GO(4); else if (nb == 2) GO(2); else GO(1);
 #undef GO2
 #undef GO
-  if (any_split) hipLaunchKernelGGL(splitk_finish_group_f32, dim3((unsigned)max_finish, count), dim3(256), 0, s, g, Y);
+  if (any_split) hipLaunchKernelGGL(splitk_finish_group_f32, dim3((unsigned)max_finish, count), dim3(256), 0, s, g, Y, aux);
   return hipGetLastError();
 }
 

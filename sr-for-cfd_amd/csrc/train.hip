@@ -460,6 +460,7 @@ struct Trainer {
   struct StepGraph { StepKey key; int seen = 0; hipGraphExec_t exec = nullptr; };
   std::vector<StepGraph> graphs;                   // at most 8 keys (full batches, the ragged last batch, ...)
   bool use_graph = true;                           // SRCFD_TRAIN_GRAPH=0: plain launches
+  bool fuse_epilogues = true;                      // SRCFD_TRAIN_FUSE=0: stand-alone swish_fwd / swish_bwd passes
   hipStream_t cap_stream = nullptr;
   float* d_xs = nullptr; float* d_ys = nullptr; size_t x_elems = 0, y_elems = 0;   // per-sample sizes of the staging buffers
   float* d_part = nullptr; size_t part_elems = 0;
@@ -643,6 +644,7 @@ static int trainer_build(Trainer& t, const Model& model, int max_batch) {
   for (auto*& b : t.dbuf) HIPCHECK(hipMalloc(&b, (size_t)max_batch * maxe * sizeof(float)));
   { const char* e = getenv("SRCFD_TRAIN_OVERLAP"); t.overlap = !(e && atoi(e) == 0); }
   { const char* e = getenv("SRCFD_TRAIN_GRAPH"); t.use_graph = !(e && atoi(e) == 0); }
+  { const char* e = getenv("SRCFD_TRAIN_FUSE"); t.fuse_epilogues = !(e && atoi(e) == 0); }
   if (t.use_graph) {
     t.x_elems = t.layers.front().in_elems; t.y_elems = t.layers.back().out_elems;
     HIPCHECK(hipMalloc(&t.d_xs, (size_t)max_batch * t.x_elems * sizeof(float)));
@@ -699,10 +701,15 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
       ++cnt;
     }
     const float* X = op.layer == 0 ? x : t.Y[op.layer - 1];
-    HIPCHECK(launch_gemm_mfma_group(ds, cnt, X, Bs, biases, t.Z[op.layer], s, t.d_splitk, t.splitk_floats, false));
+    // swish layers: the GEMM epilogue stores both Z and swish(Z) (EpiAux mode 1) when every GEMM of the layer takes it
+    bool fuse = t.fuse_epilogues && t.layers[op.layer].swish;
+    for (int q = 0; fuse && q < cnt; ++q) fuse = gemm_supports_epi_aux(ds[q]);
+    EpiAux aux;
+    if (fuse) { aux.mode = 1; aux.y2 = t.Y[op.layer]; }
+    HIPCHECK(launch_gemm_mfma_group(ds, cnt, X, Bs, biases, t.Z[op.layer], s, t.d_splitk, t.splitk_floats, false, aux));
     i = j;
     const bool last_of_layer = i == t.ops.size() || t.ops[i].layer != op.layer;
-    if (last_of_layer && t.layers[op.layer].swish) {
+    if (last_of_layer && t.layers[op.layer].swish && !fuse) {
       int64_t e = (int64_t)n * t.layers[op.layer].out_elems;
       hipLaunchKernelGGL(swish_fwd_f32, grid(e), dim3(256), 0, s, t.Z[op.layer], t.Y[op.layer], e);
     }
@@ -717,11 +724,13 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
   //    gradients, each waiting only for its layer's dZ.  dZ buffers rotate through a ring of three, so the data-gradient
   //    chain may run two layers ahead of the weight gradients before it has to wait for one of them.
   int cur = 0;
+  bool dz_done = false;  // the data-gradient GEMM below already multiplied by swish'(Z) of the layer it feeds (EpiAux mode 2)
   hipStream_t ws = t.overlap ? t.aux : s;
   for (int li = L - 1; li >= 0; --li) {
     float* dZ = t.dbuf[cur];
     int64_t e = (int64_t)n * t.layers[li].out_elems;
-    if (t.layers[li].swish) hipLaunchKernelGGL(swish_bwd_f32, grid(e), dim3(256), 0, s, t.Z[li], dZ, e);
+    if (t.layers[li].swish && !dz_done) hipLaunchKernelGGL(swish_bwd_f32, grid(e), dim3(256), 0, s, t.Z[li], dZ, e);
+    dz_done = false;
     if (t.overlap) {
       HIPCHECK(hipEventRecord(t.ev_dz[li], s));
       HIPCHECK(hipStreamWaitEvent(t.aux, t.ev_dz[li], 0));
@@ -747,7 +756,9 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
       const int nxt = (cur + 1) % 3;
       // the ring slot about to be overwritten held dZ of layer li+2: its weight gradient must have read it
       if (t.overlap && li + 2 <= L - 1) HIPCHECK(hipStreamWaitEvent(s, t.ev_wg[li + 2], 0));
-      HIPCHECK(launch_gemm_mfma(d, dZ, t.d_dpack + dg.w_off, t.d_zero_bias, t.dbuf[nxt], s, t.d_splitk, t.splitk_floats, false));
+      EpiAux aux;
+      if (t.fuse_epilogues && t.layers[li - 1].swish && gemm_supports_epi_aux(d)) { aux.mode = 2; aux.zaux = t.Z[li - 1]; dz_done = true; }
+      HIPCHECK(launch_gemm_mfma(d, dZ, t.d_dpack + dg.w_off, t.d_zero_bias, t.dbuf[nxt], s, t.d_splitk, t.splitk_floats, false, aux));
       cur = nxt;
     }
   }
