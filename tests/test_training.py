@@ -175,6 +175,40 @@ def test_fit_from_keras_default_init_on_the_dummy_recipe(srcfd):
 
 
 @pytest.mark.gpu
+def test_step_variants_give_identical_parameters(srcfd, monkeypatch):
+    """The step's structure (weight gradients on a second stream, swish / swish' folded into GEMM epilogues, replay as a
+    hipGraph from the second identical call on) must not change a bit of the result: five Adam steps on moving x / y
+    tensors with a ragged step in the middle, every switch off vs the default."""
+    require_gpu(srcfd)
+    import torch
+    tr = importlib.import_module("sr-for-cfd_amd.train")
+    synth = importlib.import_module("sr-for-cfd_amd.synth")
+    enc, dec = synth.keras_default_init(3)
+    rng = np.random.default_rng(8)
+    batches = []
+    for n in (4, 4, 3, 4, 4, 3):  # the 3-sample key comes back: it is captured on its second sighting too
+        batches.append((rng.standard_normal((n, 10, 10, 1)).astype(np.float32), rng.standard_normal((n, 400, 400, 1)).astype(np.float32)))
+
+    def run(env):
+        for k in ("SRCFD_TRAIN_OVERLAP", "SRCFD_TRAIN_FUSE", "SRCFD_TRAIN_GRAPH"):
+            monkeypatch.setenv(k, env)
+        t = tr.Trainer(srcfd.SRModel.from_weights(enc, dec, device=0), max_batch=4)
+        losses = []
+        keep = []  # hold earlier batches so that later ones land at new addresses
+        for x, y in batches:
+            xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+            keep.append((xd, yd))
+            losses.append(float(t.step(xd, yd)))
+        return losses, {k: v.copy() for k, v in t.weights().items()}
+
+    base_l, base_w = run("0")
+    l, w = run("1")
+    assert l == base_l
+    for k in base_w:
+        assert np.array_equal(w[k], base_w[k]), k
+
+
+@pytest.mark.gpu
 def test_training_driver_end_to_end(srcfd, tmp_path):
     """The notebook's __main__ (c374-604) in miniature: files -> split -> fit -> evaluate -> the three artefacts,
     which then load through the same path the solvers use."""
