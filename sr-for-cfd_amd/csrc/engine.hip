@@ -179,6 +179,7 @@ int Model::chunk_cap() const {
 int Model::ensure_workspace(int n) {
   int chunk = std::min(n, chunk_cap());
   if (chunk <= ws_chunk) return SRCFD_OK;
+  drop_graph();  // a captured forward holds the old buffers' addresses
   for (int i = 0; i < 2; ++i) if (buf[i]) { HIPCHECK(hipFree(buf[i])); buf[i] = nullptr; }
   ws_chunk = 0;
   size_t bytes = (size_t)chunk * max_act_elems() * sizeof(float);
@@ -278,24 +279,46 @@ int Model::predict_device(const void* x_dev, int n, const float* aff_in, const f
   HIPCHECK(hipSetDevice(device));
   prof_used = 0;
   const bool fused = (precision == SRCFD_PREC_BF16 || precision == SRCFD_PREC_F16);
-  if (fused) {
-    if (!has_fused) { set_error("bf16/f16 precision needs the encoder_10+decoder_400 layer graph; use SRCFD_PREC_FP32 for other graphs"); return SRCFD_EINVAL; }
-    // measured on MI355X: replay is no faster than plain launches here (0.904 vs 0.894 ms per batch; the
-    // gaps between these seven kernels are not host-bound), so it is opt-in
-    static const bool graphs = [] { const char* e = getenv("SRCFD_GRAPH"); return e && atoi(e) != 0; }();
+  if (fused && !has_fused) { set_error("bf16/f16 precision needs the encoder_10+decoder_400 layer graph; use SRCFD_PREC_FP32 for other graphs"); return SRCFD_EINVAL; }
+  if (!fused) {
+    int rc = ensure_workspace(n);  // (re)allocates before anything is captured; drops a stale graph when it does
+    if (rc) return rc;
+  }
+  const int in_elems = desc.in_shape[0] * desc.in_shape[1] * desc.in_shape[2];
+  const int* os = desc.out_shape();
+  const size_t out_elems = (size_t)os[0] * os[1] * os[2];
+  const size_t osz = out_dtype == SRCFD_F32 ? 4 : 2;
+  auto run = [&](hipStream_t st) -> int {
+    if (fused) return fused_forward(*this, (const float*)x_dev, n, aff_in, aff_out, y_dev, out_dtype, flags, nonfinite, st);
+    for (int i = 0; i < n; i += ws_chunk) {
+      int c = std::min(ws_chunk, n - i);
+      int rc = forward_generic((const float*)x_dev + (size_t)i * in_elems, c, aff_in ? aff_in + 2 * (size_t)i : nullptr,
+                               aff_out ? aff_out + 2 * (size_t)i : nullptr, (char*)y_dev + (size_t)i * out_elems * osz, out_dtype, flags,
+                               nonfinite, st);
+      if (rc) return rc;
+    }
+    return SRCFD_OK;
+  };
+  // hipGraph replay of the whole forward.  Measured on MI355X: at batch 256 replay is no faster than plain launches
+  // (0.904 vs 0.894 ms: the gaps between the kernels are not host-bound), but a solver-side call of a few samples is
+  // a chain of 8-16 kernels of 4-30 us each and replay takes ~20 us off it (bf16 one-field call 0.214 -> 0.195 ms).
+  // Default: small batches only; SRCFD_GRAPH=0 never, SRCFD_GRAPH=1 always.
+  static const int graph_env = [] { const char* e = getenv("SRCFD_GRAPH"); return e ? (atoi(e) != 0 ? 1 : 0) : -1; }();
+  const bool graphs = !profiling && (graph_env == 1 || (graph_env == -1 && n <= 96));
+  if (graphs) {
     GraphKey key;
     key.x = x_dev; key.y = y_dev; key.ain = aff_in; key.aout = aff_out; key.nf = nonfinite; key.n = n;
     key.out_dtype = out_dtype; key.flags = flags; key.precision = precision;
-    if (graphs && !profiling && graph_exec && key == graph_key) {
+    if (graph_exec && key == graph_key) {
       HIPCHECK(hipGraphLaunch(graph_exec, s));
       return SRCFD_OK;
     }
-    if (graphs && !profiling && key == last_key && !(key == graph_key)) {
+    if (key == last_key && !(key == graph_key)) {
       // second identical call: every buffer and attribute is set up, so the launches can be captured
       drop_graph();
       if (!graph_stream) HIPCHECK(hipStreamCreateWithFlags(&graph_stream, hipStreamNonBlocking));
       HIPCHECK(hipStreamBeginCapture(graph_stream, hipStreamCaptureModeThreadLocal));
-      int rc = fused_forward(*this, (const float*)x_dev, n, aff_in, aff_out, y_dev, out_dtype, flags, nonfinite, graph_stream);
+      int rc = run(graph_stream);
       hipGraph_t g = nullptr;
       hipError_t e = hipStreamEndCapture(graph_stream, &g);
       if (rc == SRCFD_OK && e == hipSuccess && g) {
@@ -311,22 +334,8 @@ int Model::predict_device(const void* x_dev, int n, const float* aff_in, const f
       (void)hipGetLastError();  // capture not possible here: fall through to plain launches
     }
     last_key = key;
-    return fused_forward(*this, (const float*)x_dev, n, aff_in, aff_out, y_dev, out_dtype, flags, nonfinite, s);
   }
-  int rc = ensure_workspace(n);
-  if (rc) return rc;
-  const int in_elems = desc.in_shape[0] * desc.in_shape[1] * desc.in_shape[2];
-  const int* os = desc.out_shape();
-  const size_t out_elems = (size_t)os[0] * os[1] * os[2];
-  const size_t osz = out_dtype == SRCFD_F32 ? 4 : 2;
-  for (int i = 0; i < n; i += ws_chunk) {
-    int c = std::min(ws_chunk, n - i);
-    rc = forward_generic((const float*)x_dev + (size_t)i * in_elems, c, aff_in ? aff_in + 2 * (size_t)i : nullptr,
-                         aff_out ? aff_out + 2 * (size_t)i : nullptr, (char*)y_dev + (size_t)i * out_elems * osz, out_dtype, flags,
-                         nonfinite, s);
-    if (rc) return rc;
-  }
-  return SRCFD_OK;
+  return run(s);
 }
 
 int Model::predict_host(const float* x, int n, const float* aff_in, const float* aff_out, float* y, int flags, int64_t* n_nonfinite,

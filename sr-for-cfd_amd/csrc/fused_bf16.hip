@@ -287,6 +287,7 @@ int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, cons
   const Pack16& P = fs->packs[f16 ? 1 : 0];
   const int want = std::min(n, 1024);
   if (want > fs->cap) {
+    m.drop_graph();  // a captured forward holds the old buffers' addresses
     for (auto*& b : fs->act) if (b) { HIPCHECK(hipFree(b)); b = nullptr; }
     fs->cap = 0;
     for (auto*& b : fs->act) HIPCHECK(hipMalloc(&b, (size_t)want * ACT_ELEMS * sizeof(uint16_t)));

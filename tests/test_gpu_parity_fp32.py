@@ -234,3 +234,34 @@ def test_predict_into_preallocated_output(srcfd, enc_weights):
         m.predict(x, out=np.empty((4, 1, 1, 50), np.float32))
     with pytest.raises(ValueError):
         m.predict(x, out=np.empty((5, 1, 1, 50), np.float64))
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_graph_replay_survives_buffer_growth(srcfd, enc_weights, dec_weights, precision):
+    """Small batches are replayed as a hipGraph from the third identical call on (engine.hip).  A larger batch in between
+    re-allocates the activation buffers the graph points at: it must be dropped and re-captured, never replayed stale."""
+    require_gpu(srcfd)
+    m = srcfd.SRModel.from_weights(enc_weights, dec_weights, device=0)
+    m.precision = precision
+    rng = np.random.default_rng(12)
+    x3 = rng.standard_normal((3, 10, 10, 1)).astype(np.float32)
+    x5 = rng.standard_normal((5, 10, 10, 1)).astype(np.float32)
+    big = rng.standard_normal((130, 10, 10, 1)).astype(np.float32)
+    first = m.predict(x3)                                   # plain launches
+    for _ in range(3):                                      # capture, then replays
+        np.testing.assert_array_equal(m.predict(x3), first)
+    y5 = m.predict(x5)                                      # another key in between
+    np.testing.assert_array_equal(m.predict(x3), first)
+    ybig = m.predict(big)                                   # grows every buffer
+    for _ in range(4):
+        np.testing.assert_array_equal(m.predict(x3), first)
+    for _ in range(3):
+        np.testing.assert_array_equal(m.predict(x5), y5)
+    np.testing.assert_array_equal(m.predict(big)[:3], ybig[:3])
+    # new inputs through the same staging buffers: a replay must read them, not the captured call's data
+    x3b = rng.standard_normal((3, 10, 10, 1)).astype(np.float32)
+    for _ in range(3):
+        m.predict(x3)
+    yb = m.predict(x3b)
+    assert not np.array_equal(yb, first)
+    np.testing.assert_array_equal(m.predict(np.concatenate([x3b, x5]))[:3], yb)
