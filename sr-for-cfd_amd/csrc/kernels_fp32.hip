@@ -15,6 +15,7 @@
 
 #include <algorithm>
 
+#include "act_device.h"
 #include "kernels.h"
 
 namespace srcfd {
@@ -47,13 +48,6 @@ __device__ __forceinline__ float act_apply_precise(float v, int act) {
     return v * r;
   }
   return act_apply(v, act);
-}
-
-// training epilogues (EpiAux): the expressions of train.hip's swish_fwd_f32 / swish_bwd_f32
-__device__ __forceinline__ float swish_train(float v) { return v / (1.0f + expf(-v)); }
-__device__ __forceinline__ float swish_grad_train(float z) {
-  float s = 1.0f / (1.0f + expf(-z));
-  return s + z * s * (1.0f - s);
 }
 
 __device__ __forceinline__ void row_decode(const GemmDesc& d, int m, int& img, int& my, int& mx) {

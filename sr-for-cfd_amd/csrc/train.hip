@@ -24,6 +24,7 @@
 #include <string>
 #include <vector>
 
+#include "act_device.h"
 #include "engine.h"
 
 namespace srcfd {
@@ -44,16 +45,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) swish_fwd_f32(const float* __restrict__ z, float* __restrict__ y, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) { float v = z[i]; y[i] = v / (1.0f + expf(-v)); }
+  if (i < n) y[i] = swish_train(z[i]);
 }
 
 // dz = dy * swish'(z), swish'(z) = s + z s (1 - s), s = sigmoid(z); in place on dy
 __global__ void __launch_bounds__(256) swish_bwd_f32(const float* __restrict__ z, float* __restrict__ dy, int64_t n) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) {
-    float v = z[i], s = 1.0f / (1.0f + expf(-v));
-    dy[i] *= s + v * s * (1.0f - s);
-  }
+  if (i < n) dy[i] *= swish_grad_train(z[i]);
 }
 
 // dpred = 2 * scale * (pred - y); per-block partial sums of squared error (fixed order -> reproducible)
