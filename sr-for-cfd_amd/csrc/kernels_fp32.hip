@@ -41,12 +41,7 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 // this form is ~8 and moves the result by a few 1e-7 relative, an order of magnitude below the f32 accumulation-order
 // differences against the float64 oracle (tests: 1e-5 bar).
 __device__ __forceinline__ float act_apply_precise(float v, int act) {
-  if (act == SRCFD_ACT_SWISH) {
-    const float den = 1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f);
-    float r = __builtin_amdgcn_rcpf(den);
-    r = fmaf(fmaf(-den, r, 1.0f), r, r);
-    return v * r;
-  }
+  if (act == SRCFD_ACT_SWISH) return v * sigmoid_fast(v);  // act_device.h (overflow-safe Newton step)
   return act_apply(v, act);
 }
 

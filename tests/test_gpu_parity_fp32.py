@@ -265,3 +265,46 @@ def test_graph_replay_survives_buffer_growth(srcfd, enc_weights, dec_weights, pr
     yb = m.predict(x3b)
     assert not np.array_equal(yb, first)
     np.testing.assert_array_equal(m.predict(np.concatenate([x3b, x5]))[:3], yb)
+
+
+def test_swish_of_extreme_pre_activations_is_finite(srcfd, oracle):
+    """z < -88 overflows exp2(-z log2e) to inf; the Newton-refined reciprocal must not turn that into NaN (found by
+    tools/soak.py: 2000 training steps).  swish(-200) is -0 in float32, swish(200) is 200.  Conv, Dense and the
+    single-output-channel kernels all go through the same activation."""
+    require_gpu(srcfd)
+    z = np.array([-1e4, -200.0, -130.0, -100.0, -88.8, -88.0, -50.0, -1.0, 0.0, 1.0, 50.0, 200.0, 1e4, 3e38, -3e38], np.float32)
+    eye = np.eye(len(z), dtype=np.float32)
+    specs = [dict(kind="flatten"), dict(kind="dense", act="swish", w=eye, b=np.zeros(len(z), np.float32))]
+    x = np.stack([z, z[::-1]]).reshape(2, 1, 1, len(z))
+    ref = oracle.dense(x.reshape(2, -1).astype(np.float64), eye, np.zeros(len(z)), "swish")
+    for prec in ("fp32_naive", "fp32"):
+        m = srcfd.SRModel.from_layers(specs, (1, 1, len(z)), device=0)
+        m.precision = prec
+        y = m.predict(x).reshape(2, -1)
+        assert np.isfinite(y).all(), (prec, y)
+        np.testing.assert_allclose(y, ref, rtol=2e-6, atol=1e-30)
+    # a 3x3 conv to one channel (the output-conv kernels) with a swish, fed a constant -40 image: z = 9 * -40 * 1 = -360
+    w = np.ones((3, 3, 8, 1), np.float32)
+    specs = [dict(kind="conv2d", k=3, stride=1, same=True, act="swish", w=w, b=np.zeros(1, np.float32))]
+    img = np.full((1, 16, 16, 8), -5.0, np.float32)
+    for prec in ("fp32_naive", "fp32"):
+        m = srcfd.SRModel.from_layers(specs, (16, 16, 8), device=0)
+        m.precision = prec
+        y = m.predict(img)
+        assert np.isfinite(y).all() and np.abs(y).max() < 1e-30, (prec, y.min(), y.max())
+
+
+def test_full_model_with_far_out_of_range_inputs(srcfd, oracle, enc_weights, dec_weights):
+    """Inputs 200 standard deviations out drive pre-activations far below -88 all through the network: the f32 path
+    must still match the float64 oracle, and the 16-bit paths must stay finite wherever the oracle is."""
+    require_gpu(srcfd)
+    rng = np.random.default_rng(31)
+    x = (rng.standard_normal((4, 10, 10, 1)) * 200.0).astype(np.float32)
+    ref = oracle.superres_forward(x, enc_weights, dec_weights, np.float64)
+    assert np.isfinite(ref).all()
+    m = srcfd.SRModel.from_weights(enc_weights, dec_weights, device=0)
+    for prec, tol in (("fp32", TOL_FP32), ("f16", 5e-3), ("bf16", 3e-2)):
+        m.precision = prec
+        y = m.predict(x)
+        assert np.isfinite(y).all(), prec
+        assert oracle.rel_l2(y, ref) <= tol, (prec, oracle.rel_l2(y, ref))
