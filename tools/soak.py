@@ -44,6 +44,21 @@ def main():
         print(f"{prec}: {args.calls} calls, {dt / args.calls * 1e3:.4f} ms/call, device memory change {leak} B")
         assert leak <= 0, leak
         del m
+    # random batch sizes and sample subsets: graph capture / drop / re-capture, buffer growth, tail segmentation choices --
+    # every row must equal the row of a one-off reference run, bit for bit (batch invariance)
+    pool = rng.standard_normal((40, 10, 10, 1)).astype(np.float32)
+    for prec in ("bf16", "f16", "fp32"):
+        m = srcfd.SRModel.from_weights(enc, dec, device=0)
+        m.precision = prec
+        ref = m.predict(pool)
+        sizes = [1, 1, 3, 3, 3, 2, 7, 7, 7, 40, 3, 3, 3, 16, 16, 16, 5, 130, 3, 3, 3]
+        for it in range(args.calls // 40):
+            n = sizes[it % len(sizes)] if it < 3 * len(sizes) else int(rng.integers(1, 24))
+            idx = rng.integers(0, 40, size=min(n, 40)) if n <= 40 else rng.integers(0, 40, size=n)
+            y = m.predict(pool[idx])
+            assert np.array_equal(y, ref[idx]), (prec, it, n)
+        print(f"{prec}: {args.calls // 40} random-size calls bit-identical to the reference rows")
+        del m
     t = tr.Trainer(srcfd.SRModel.from_weights(enc, dec, device=0), max_batch=8)
     xs = torch.from_numpy(rng.standard_normal((8, 10, 10, 1)).astype(np.float32)).cuda()
     ys = torch.from_numpy(rng.standard_normal((8, 400, 400, 1)).astype(np.float32)).cuda()
