@@ -164,6 +164,24 @@ def test_harness_bfs_with_resampling_and_blend_matches_reference_recipe(srcfd, o
 
 
 @pytest.mark.gpu
+def test_verbose_call_prints_the_reference_style_report_and_same_fields(srcfd, decoder_h5, coarse_cases, capsys):
+    """verbose=True reports the blended statistics and the range of every component (the reference prints them on every
+    call, bfs_ml_accelerated.py:1096-1145); the quiet default skips those range scans but returns the same arrays."""
+    require_gpu(srcfd)
+    pl = importlib.import_module("sr-for-cfd_amd.pipeline")
+    case = coarse_cases["bfs_Re400"]
+    kw = dict(use_aspect_ratio_correction=True, lx=10.0, ly=3.0, blend_factor=0.3)
+    quiet = pl.ml_super_resolution_bfs(case, 10, 400, STATS_TXT, ENCODER_H5, decoder_h5, **kw)
+    assert capsys.readouterr().out == ""
+    loud = pl.ml_super_resolution_bfs(case, 10, 400, STATS_TXT, ENCODER_H5, decoder_h5, verbose=True, **kw)
+    text = capsys.readouterr().out
+    for c in ("u", "v", "p"):
+        np.testing.assert_array_equal(loud[c], quiet[c])
+        assert f"{c.upper()}: adaptive norm (blend=0.30)" in text
+        assert f"range [{loud[c].min():.6f}, {loud[c].max():.6f}]" in text
+
+
+@pytest.mark.gpu
 def test_tiled_sr_config5(srcfd, oracle, enc_weights, dec_weights):
     """40x40x3 -> 1600x1600x3 through 4x4 tiles (BASELINE config 5), f16 operands."""
     require_gpu(srcfd)
