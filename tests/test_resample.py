@@ -60,3 +60,15 @@ def test_device_resampling_matches_scipy(srcfd):
     got = rs.Resampler(Ry, Rx, 0).apply_device(torch.from_numpy(g).cuda()).cpu().numpy()
     want = np.einsum("oh,zhw,pw->zop", Ry, g.astype(np.float64), Rx)
     assert np.abs(got - want).max() <= 1e-12 * np.abs(want).max()
+    # random small shapes: every edge of the 32x32 MFMA tiles, K not a multiple of 4, one identity factor skipped
+    for it in range(40):
+        H, W, OH, OW = [int(v) for v in rng.integers(1, 70, size=4)]
+        Ry, Rx = rng.standard_normal((OH, H)), rng.standard_normal((OW, W))
+        if it % 4 == 1:
+            Ry, OH = np.eye(H), H
+        if it % 4 == 2:
+            Rx, OW = np.eye(W), W
+        g = rng.standard_normal((int(rng.integers(1, 4)), H, W)).astype(np.float32)
+        got = rs.Resampler(Ry, Rx, 0).apply_device(torch.from_numpy(g).cuda()).cpu().numpy()
+        want = np.einsum("oh,zhw,pw->zop", Ry, g.astype(np.float64), Rx)
+        assert got.shape == want.shape and np.abs(got - want).max() <= 1e-12 * max(np.abs(want).max(), 1.0), (it, H, W, OH, OW)
