@@ -278,9 +278,9 @@ int Model::predict_device(const void* x_dev, int n, const float* aff_in, const f
   if (n == 0) return SRCFD_OK;
   HIPCHECK(hipSetDevice(device));
   prof_used = 0;
-  const bool fused = (precision == SRCFD_PREC_BF16 || precision == SRCFD_PREC_F16);
-  if (fused && !has_fused) { set_error("bf16/f16 precision needs the encoder_10+decoder_400 layer graph; use SRCFD_PREC_FP32 for other graphs"); return SRCFD_EINVAL; }
-  if (!fused) {
+  const bool use_fused = (precision == SRCFD_PREC_BF16 || precision == SRCFD_PREC_F16);
+  if (use_fused && !has_fused) { set_error("bf16/f16 precision needs the encoder_10+decoder_400 layer graph; use SRCFD_PREC_FP32 for other graphs"); return SRCFD_EINVAL; }
+  if (!use_fused) {
     int rc = ensure_workspace(n);  // (re)allocates before anything is captured; drops a stale graph when it does
     if (rc) return rc;
   }
@@ -289,7 +289,7 @@ int Model::predict_device(const void* x_dev, int n, const float* aff_in, const f
   const size_t out_elems = (size_t)os[0] * os[1] * os[2];
   const size_t osz = out_dtype == SRCFD_F32 ? 4 : 2;
   auto run = [&](hipStream_t st) -> int {
-    if (fused) return fused_forward(*this, (const float*)x_dev, n, aff_in, aff_out, y_dev, out_dtype, flags, nonfinite, st);
+    if (use_fused) return fused_forward(*this, (const float*)x_dev, n, aff_in, aff_out, y_dev, out_dtype, flags, nonfinite, st);
     for (int i = 0; i < n; i += ws_chunk) {
       int c = std::min(ws_chunk, n - i);
       int rc = forward_generic((const float*)x_dev + (size_t)i * in_elems, c, aff_in ? aff_in + 2 * (size_t)i : nullptr,
