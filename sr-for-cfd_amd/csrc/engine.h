@@ -39,6 +39,10 @@ struct Model {
 
   std::vector<Op> ops;
   std::vector<float> pack;  // host copy of packed weights
+  // ops[pair_op], ops[pair_op + 1]: two kernel == stride == 2 transposed convolutions (32 -> 16 -> 8 channels) that run as
+  // one kernel (kernels.h, PairDesc); -1: none.  Offsets into `pack`.
+  int pair_op = -1;
+  size_t pair_wa = 0, pair_ba = 0, pair_wb = 0, pair_bb = 0;
   float* d_pack = nullptr;
 
   float* buf[2] = {nullptr, nullptr};

@@ -121,6 +121,42 @@ void build_plan(const ModelDesc& desc, std::vector<Op>& ops, std::vector<float>&
   }
 }
 
+// Operands of the fused ConvT pair (kernels_fp32.hip, convt_pair_f32), appended to `pack`:
+//   wa[(T*16 + s)*64 + lane]: first layer, row i = lane & 31 of tile T -> tap 2T + (i >> 4), channel i & 15; k = 16 (lane >> 5) + s
+//   wb[u*64 + lane]:          second layer, row j = lane & 31 -> tap j >> 3, channel j & 7; k = (u & 3) + 8 (u >> 2) + 4 (lane >> 5)
+// Conv2DTranspose kernels are (kh, kw, Cout, Cin).
+static void plan_convt_pair(Model& m) {
+  m.pair_op = -1;
+  for (size_t i = 0; i + 1 < m.ops.size(); ++i) {
+    const Op &a = m.ops[i], &b = m.ops[i + 1];
+    const Layer &La = m.desc.layers[a.layer], &Lb = m.desc.layers[b.layer];
+    auto is_k2s2 = [](const Layer& L) { return L.kind == SRCFD_LAYER_CONV2D_TRANSPOSE && L.kh == 2 && L.kw == 2 && L.stride == 2; };
+    if (a.layer + 1 != b.layer || !is_k2s2(La) || !is_k2s2(Lb)) continue;
+    if (a.d.nphx != 2 || b.d.nphx != 2) continue;  // one op per layer (the merged-phase form)
+    if (La.cin != 32 || La.cout != 16 || Lb.cin != 16 || Lb.cout != 8) continue;
+    auto& pk = m.pack;
+    auto align = [&]() { while (pk.size() % 64) pk.push_back(0.f); };
+    align(); m.pair_wa = pk.size(); pk.resize(pk.size() + 2 * 16 * 64);
+    for (int T = 0; T < 2; ++T)
+      for (int s = 0; s < 16; ++s)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int row = lane & 31, tap = 2 * T + (row >> 4), ch = row & 15, k = 16 * (lane >> 5) + s;
+          pk[m.pair_wa + (size_t)(T * 16 + s) * 64 + lane] = La.kernel[((size_t)tap * 16 + ch) * 32 + k];
+        }
+    align(); m.pair_ba = pk.size(); pk.insert(pk.end(), La.bias.begin(), La.bias.end());
+    align(); m.pair_wb = pk.size(); pk.resize(pk.size() + 8 * 64);
+    for (int u = 0; u < 8; ++u)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int row = lane & 31, tap = row >> 3, ch = row & 7, k = (u & 3) + 8 * (u >> 2) + 4 * (lane >> 5);
+        pk[m.pair_wb + (size_t)u * 64 + lane] = Lb.kernel[((size_t)tap * 8 + ch) * 16 + k];
+      }
+    align(); m.pair_bb = pk.size(); pk.insert(pk.end(), Lb.bias.begin(), Lb.bias.end());
+    align();
+    m.pair_op = (int)i;
+    return;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // model
 // ---------------------------------------------------------------------------
@@ -244,6 +280,19 @@ int Model::forward_generic(const float* x_dev, int n, const float* aff_in, const
       return launch(op.name.c_str(), s, [&] {
         return launch_gemm_finalize(d, X, B, bias, y_dev, out_dtype, aff_out, flags & SRCFD_FLAG_NAN_GUARD, nonfinite, s);
       });
+    }
+    static const bool no_pair = [] { const char* e = getenv("SRCFD_NO_PAIR"); return e && atoi(e) != 0; }();
+    if (!naive && !no_pair && (int)i == pair_op && i + 2 < ops.size()) {  // ConvT#3 -> ConvT#4 in one kernel (kernels.h, PairDesc)
+      PairDesc pd;
+      pd.n = n; pd.H = d.MH; pd.W = d.MW; pd.act_a = d.act; pd.act_b = ops[i + 1].d.act;
+      const std::string nm = op.name + "+" + ops[i + 1].name;
+      rc = launch(nm.c_str(), s, [&] {
+        return launch_convt_pair_f32(pd, X, d_pack + pair_wa, d_pack + pair_ba, d_pack + pair_wb, d_pack + pair_bb, Y, s);
+      });
+      if (rc) return rc;
+      prev_layer = ops[i + 1].layer;  // the pair's output sits where the first layer's would: the next layer toggles once
+      ++i;
+      continue;
     }
     size_t j = i + 1;
     while (j < ops.size() && ops[j].layer == op.layer && j - i < 4) ++j;
@@ -384,6 +433,7 @@ static int finish_create(std::unique_ptr<Model>& m, srcfd_model** out) {
   try {
     m->desc.infer_shapes();
     build_plan(m->desc, m->ops, m->pack);
+    plan_convt_pair(*m);
   } catch (const std::exception& e) {
     set_error(e.what());
     return SRCFD_EINVAL;

@@ -44,6 +44,16 @@ size_t gemm_splitk_ws_floats(const GemmDesc& d, bool batch_invariant = true);
 hipError_t launch_gemm_mfma_group(const GemmDesc* ds, int count, const float* X, const float* const* Bs, const float* const* biases, float* Y,
                                   hipStream_t s, float* ws, size_t ws_floats, bool batch_invariant = true, EpiAux aux = EpiAux());
 size_t gemm_group_ws_floats(const GemmDesc* ds, int count, bool batch_invariant = true);
+// Two consecutive kernel == stride == 2 transposed convolutions (CI 32 -> 16 -> 8 channels: ConvT#3 -> ConvT#4 of
+// decoder_400) as one kernel: every input pixel expands to its own 4 x 4 output block, no halo, so the 16-channel
+// intermediate (0.65 GB written + read per 256 samples, these two layers are HBM-bound) never leaves the registers.
+struct PairDesc {
+  int n, H, W;         // input (n, H, W, 32); output (n, 4H, 4W, 8)
+  int act_a, act_b;
+};
+// wa [2 tiles][16 k-steps][64 lanes], ba [16], wb [8 k-steps][64 lanes], bb [8]: see pack_convt_pair() in engine.hip
+hipError_t launch_convt_pair_f32(const PairDesc& d, const float* X, const float* wa, const float* ba, const float* wb, const float* bb,
+                                 float* Y, hipStream_t s);
 // Last layer + de-standardise + NaN guard + output cast in one kernel, for the layers gemm_fuses_finalize() accepts.
 bool gemm_fuses_finalize(const GemmDesc& d);
 hipError_t launch_gemm_finalize(const GemmDesc& d, const float* X, const float* B, const float* bias, void* out, int out_dtype,

@@ -783,6 +783,82 @@ hipError_t launch_gemm_mfma_group(const GemmDesc* ds, int count, const float* X,
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------
+// ConvT (2x2, s2, 32 -> 16) chained into ConvT (2x2, s2, 16 -> 8), f32 (kernels.h, PairDesc).
+// Transposed formulation: D = W^T (rows = tap x channel) * X^T (columns = 32 pixels of the wave), so the swished
+// accumulators of the first GEMM -- lane (pixel, h) holds rows (r&3) + 8(r>>2) + 4h -- ARE the B operands of the second
+// one (k-step u contracts channels (u&3) + 8(u>>2) + 4h; the weights are packed in that order on the host).  All 40
+// A-operand registers (both layers' weights) stay resident while the wave walks its pixel groups.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) convt_pair_f32(PairDesc d, const float* __restrict__ X, const float* __restrict__ wa,
+                                                       const float* __restrict__ ba, const float* __restrict__ wb,
+                                                       const float* __restrict__ bb, float* __restrict__ Y) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, l31 = lane & 31;
+  float wA[2][16], wB[8], bA[8], bB[4];
+#pragma unroll
+  for (int T = 0; T < 2; ++T)
+#pragma unroll
+    for (int s = 0; s < 16; ++s) wA[T][s] = wa[(T * 16 + s) * 64 + lane];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) wB[u] = wb[u * 64 + lane];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) bA[r] = ba[(r & 3) + 4 * h + 8 * (r >> 2)];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bB[r] = bb[r + 4 * h];
+  const int64_t M = (int64_t)d.n * d.H * d.W, groups = (M + 31) / 32;
+  const int OH = 4 * d.H, OW = 4 * d.W;
+  for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < groups; g += (int64_t)gridDim.x * 4) {
+    const int64_t m = g * 32 + l31;
+    const bool ok = m < M;
+    const int64_t mm = ok ? m : M - 1;
+    const float4* xp = reinterpret_cast<const float4*>(X + mm * 32 + 16 * h);
+    const float4 x0 = xp[0], x1 = xp[1], x2 = xp[2], x3 = xp[3];
+    const float xs[16] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w, x3.x, x3.y, x3.z, x3.w};
+    const int img = (int)(mm / ((int64_t)d.H * d.W));
+    const int rem = (int)(mm - (int64_t)img * d.H * d.W), y = rem / d.W, x = rem - y * d.W;
+    f32x16 accA[2];
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accA[T][r] = bA[(r & 3) + 4 * ((r >> 2) & 1)];
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+      for (int T = 0; T < 2; ++T) accA[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[T][s], xs[s], accA[T], 0, 0, 0);
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accA[T][r] = act_apply_precise(accA[T][r], d.act_a);
+#pragma unroll
+    for (int ta = 0; ta < 4; ++ta) {
+      const int T = ta >> 1, half = ta & 1;
+      f32x16 accB;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accB[r] = bB[r & 3];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) accB = __builtin_amdgcn_mfma_f32_32x32x2f32(wB[u], accA[T][8 * half + u], accB, 0, 0, 0);
+      // rows (r&3) + 8(r>>2) + 4h: second-layer tap r>>2, channels 4h .. 4h+3 -> one 16-byte store per tap
+      const int oy0 = 4 * y + 2 * (ta >> 1), ox0 = 4 * x + 2 * (ta & 1);
+#pragma unroll
+      for (int tb = 0; tb < 4; ++tb) {
+        const float4 v = make_float4(act_apply_precise(accB[4 * tb], d.act_b), act_apply_precise(accB[4 * tb + 1], d.act_b),
+                                     act_apply_precise(accB[4 * tb + 2], d.act_b), act_apply_precise(accB[4 * tb + 3], d.act_b));
+        if (ok) *reinterpret_cast<float4*>(Y + ((((int64_t)img * OH + oy0 + (tb >> 1)) * OW + ox0 + (tb & 1)) * 8 + 4 * h)) = v;
+      }
+    }
+  }
+}
+
+hipError_t launch_convt_pair_f32(const PairDesc& d, const float* X, const float* wa, const float* ba, const float* wb, const float* bb,
+                                 float* Y, hipStream_t s) {
+  const int64_t M = (int64_t)d.n * d.H * d.W;
+  if (M == 0) return hipSuccess;
+  const int64_t groups = (M + 31) / 32;
+  const int blocks = (int)std::min<int64_t>((groups + 3) / 4, 256 * 4);  // <= 4 resident workgroups per CU, each wave loops
+  hipLaunchKernelGGL(convt_pair_f32, dim3(blocks), dim3(256), 0, s, d, X, wa, ba, wb, bb, Y);
+  return hipGetLastError();
+}
+
 hipError_t launch_standardize(const float* x, float* y, const float* affine, int per_sample, int64_t total, hipStream_t s) {
   if (total == 0) return hipSuccess;
   hipLaunchKernelGGL(standardize_f32, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, y, affine, per_sample, total);
