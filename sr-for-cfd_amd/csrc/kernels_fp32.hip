@@ -790,6 +790,8 @@ hipError_t launch_gemm_mfma_group(const GemmDesc* ds, int count, const float* X,
 // one (k-step u contracts channels (u&3) + 8(u>>2) + 4h; the weights are packed in that order on the host).  All 40
 // A-operand registers (both layers' weights) stay resident while the wave walks its pixel groups.
 // ---------------------------------------------------------------------------
+constexpr int PAIR_PITCH = 144;  // bytes per staged pixel row (128 + 16: conflict-free 16-byte accesses)
+
 __global__ void __launch_bounds__(256) convt_pair_f32(PairDesc d, const float* __restrict__ X, const float* __restrict__ wa,
                                                        const float* __restrict__ ba, const float* __restrict__ wb,
                                                        const float* __restrict__ bb, float* __restrict__ Y) {
@@ -807,6 +809,8 @@ __global__ void __launch_bounds__(256) convt_pair_f32(PairDesc d, const float* _
   for (int r = 0; r < 4; ++r) bB[r] = bb[r + 4 * h];
   const int64_t M = (int64_t)d.n * d.H * d.W, groups = (M + 31) / 32;
   const int OH = 4 * d.H, OW = 4 * d.W;
+  __shared__ __attribute__((aligned(16))) char pair_stage[4][2 * 32 * PAIR_PITCH];
+  char* stage = pair_stage[wave];
   for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < groups; g += (int64_t)gridDim.x * 4) {
     const int64_t m = g * 32 + l31;
     const bool ok = m < M;
@@ -816,6 +820,7 @@ __global__ void __launch_bounds__(256) convt_pair_f32(PairDesc d, const float* _
     const float xs[16] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w, x2.x, x2.y, x2.z, x2.w, x3.x, x3.y, x3.z, x3.w};
     const int img = (int)(mm / ((int64_t)d.H * d.W));
     const int rem = (int)(mm - (int64_t)img * d.H * d.W), y = rem / d.W, x = rem - y * d.W;
+    const int64_t obase = ok ? (((int64_t)img * OH + 4 * y) * OW + 4 * x) * 8 : -1;
     f32x16 accA[2];
 #pragma unroll
     for (int T = 0; T < 2; ++T)
@@ -829,22 +834,38 @@ __global__ void __launch_bounds__(256) convt_pair_f32(PairDesc d, const float* _
     for (int T = 0; T < 2; ++T)
 #pragma unroll
       for (int r = 0; r < 16; ++r) accA[T][r] = act_apply_precise(accA[T][r], d.act_a);
+    // Output rows leave through a wave-private LDS tile: for one (ty_a, ty_b) output row, an input pixel owns 4 output pixels
+    // x 32 B = 128 contiguous bytes, produced by this lane pair as 8 chunks of 16 B spread over two taps and four
+    // registers.  Written as [pixel][chunk] (144-byte pitch), read back with 8 lanes per pixel, the 32 pixels of the wave
+    // store 4 KB of whole 128-byte lines instead of 32-byte pieces 128 B apart.
 #pragma unroll
-    for (int ta = 0; ta < 4; ++ta) {
-      const int T = ta >> 1, half = ta & 1;
-      f32x16 accB;
+    for (int tya = 0; tya < 2; ++tya) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) accB[r] = bB[r & 3];
+      for (int txa = 0; txa < 2; ++txa) {
+        const int ta = 2 * tya + txa, T = ta >> 1, half = ta & 1;
+        f32x16 accB;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) accB = __builtin_amdgcn_mfma_f32_32x32x2f32(wB[u], accA[T][8 * half + u], accB, 0, 0, 0);
-      // rows (r&3) + 8(r>>2) + 4h: second-layer tap r>>2, channels 4h .. 4h+3 -> one 16-byte store per tap
-      const int oy0 = 4 * y + 2 * (ta >> 1), ox0 = 4 * x + 2 * (ta & 1);
+        for (int r = 0; r < 16; ++r) accB[r] = bB[r & 3];
 #pragma unroll
-      for (int tb = 0; tb < 4; ++tb) {
-        const float4 v = make_float4(act_apply_precise(accB[4 * tb], d.act_b), act_apply_precise(accB[4 * tb + 1], d.act_b),
-                                     act_apply_precise(accB[4 * tb + 2], d.act_b), act_apply_precise(accB[4 * tb + 3], d.act_b));
-        if (ok) *reinterpret_cast<float4*>(Y + ((((int64_t)img * OH + oy0 + (tb >> 1)) * OW + ox0 + (tb & 1)) * 8 + 4 * h)) = v;
+        for (int u = 0; u < 8; ++u) accB = __builtin_amdgcn_mfma_f32_32x32x2f32(wB[u], accA[T][8 * half + u], accB, 0, 0, 0);
+        // rows (r&3) + 8(r>>2) + 4h: second-layer tap tb = r>>2 = (ty_b, tx_b), channels 4h .. 4h+3
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) {
+          const float4 v = make_float4(act_apply_precise(accB[4 * tb], d.act_b), act_apply_precise(accB[4 * tb + 1], d.act_b),
+                                       act_apply_precise(accB[4 * tb + 2], d.act_b), act_apply_precise(accB[4 * tb + 3], d.act_b));
+          *reinterpret_cast<float4*>(stage + (tb >> 1) * (32 * PAIR_PITCH) + l31 * PAIR_PITCH + (4 * txa + 2 * (tb & 1) + h) * 16) = v;
+        }
       }
+      // both taps of this ty_a are staged: rows ty_b = 0, 1.  Lane -> (pixel = lane/8 + 8q, chunk = lane%8)
+#pragma unroll
+      for (int tyb = 0; tyb < 2; ++tyb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int pix = (lane >> 3) + 8 * q;
+          const float4 v = *reinterpret_cast<const float4*>(stage + tyb * (32 * PAIR_PITCH) + pix * PAIR_PITCH + (lane & 7) * 16);
+          const int64_t base = __shfl(obase, pix, 64);   // element offset of output pixel (4y, 4x) of that lane's input pixel
+          if (base >= 0) *reinterpret_cast<float4*>(Y + base + ((int64_t)(2 * tya + tyb) * OW) * 8 + (lane & 7) * 4) = v;
+        }
     }
   }
 }
