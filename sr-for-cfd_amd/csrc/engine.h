@@ -43,6 +43,9 @@ struct Model {
   // one kernel (kernels.h, PairDesc); -1: none.  Offsets into `pack`.
   int pair_op = -1;
   size_t pair_wa = 0, pair_ba = 0, pair_wb = 0, pair_bb = 0;
+  // ops[triple_op .. +2]: the same with a 64 -> 32 layer in front (kernels.h, TripleDesc); takes precedence over the pair
+  int triple_op = -1;
+  size_t tri_w1 = 0, tri_b1 = 0, tri_w2 = 0, tri_b2 = 0, tri_w3 = 0, tri_b3 = 0;
   float* d_pack = nullptr;
 
   float* buf[2] = {nullptr, nullptr};

@@ -157,6 +157,46 @@ static void plan_convt_pair(Model& m) {
   }
 }
 
+// Operands of the three-layer chain (convt_triple_f32): w1[(T*32 + s)*64 + lane]: tap T, channel lane & 31, k = 32 (lane >> 5) + s;
+// w2[(T*16 + u)*64 + lane]: tap 2T + (row >> 4), channel row & 15, k = (u & 3) + 8 (u >> 2) + 4 (lane >> 5); w3 as the pair's wb.
+static void plan_convt_triple(Model& m) {
+  m.triple_op = -1;
+  auto is_k2s2 = [](const Layer& L) { return L.kind == SRCFD_LAYER_CONV2D_TRANSPOSE && L.kh == 2 && L.kw == 2 && L.stride == 2; };
+  for (size_t i = 0; i + 2 < m.ops.size(); ++i) {
+    const Op &a = m.ops[i], &b = m.ops[i + 1], &c = m.ops[i + 2];
+    if (a.layer + 1 != b.layer || b.layer + 1 != c.layer) continue;
+    const Layer &L1 = m.desc.layers[a.layer], &L2 = m.desc.layers[b.layer], &L3 = m.desc.layers[c.layer];
+    if (!is_k2s2(L1) || !is_k2s2(L2) || !is_k2s2(L3) || a.d.nphx != 2 || b.d.nphx != 2 || c.d.nphx != 2) continue;
+    if (L1.cin != 64 || L1.cout != 32 || L2.cin != 32 || L2.cout != 16 || L3.cin != 16 || L3.cout != 8) continue;
+    auto& pk = m.pack;
+    auto align = [&]() { while (pk.size() % 64) pk.push_back(0.f); };
+    align(); m.tri_w1 = pk.size(); pk.resize(pk.size() + 4 * 32 * 64);
+    for (int T = 0; T < 4; ++T)
+      for (int s = 0; s < 32; ++s)
+        for (int lane = 0; lane < 64; ++lane)
+          pk[m.tri_w1 + (size_t)(T * 32 + s) * 64 + lane] = L1.kernel[((size_t)T * 32 + (lane & 31)) * 64 + 32 * (lane >> 5) + s];
+    align(); m.tri_b1 = pk.size(); pk.insert(pk.end(), L1.bias.begin(), L1.bias.end());
+    align(); m.tri_w2 = pk.size(); pk.resize(pk.size() + 2 * 16 * 64);
+    for (int T = 0; T < 2; ++T)
+      for (int u = 0; u < 16; ++u)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int row = lane & 31, tap = 2 * T + (row >> 4), ch = row & 15, k = (u & 3) + 8 * (u >> 2) + 4 * (lane >> 5);
+          pk[m.tri_w2 + (size_t)(T * 16 + u) * 64 + lane] = L2.kernel[((size_t)tap * 16 + ch) * 32 + k];
+        }
+    align(); m.tri_b2 = pk.size(); pk.insert(pk.end(), L2.bias.begin(), L2.bias.end());
+    align(); m.tri_w3 = pk.size(); pk.resize(pk.size() + 8 * 64);
+    for (int u = 0; u < 8; ++u)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int row = lane & 31, tap = row >> 3, ch = row & 7, k = (u & 3) + 8 * (u >> 2) + 4 * (lane >> 5);
+        pk[m.tri_w3 + (size_t)u * 64 + lane] = L3.kernel[((size_t)tap * 8 + ch) * 16 + k];
+      }
+    align(); m.tri_b3 = pk.size(); pk.insert(pk.end(), L3.bias.begin(), L3.bias.end());
+    align();
+    m.triple_op = (int)i;
+    return;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // model
 // ---------------------------------------------------------------------------
@@ -282,6 +322,20 @@ int Model::forward_generic(const float* x_dev, int n, const float* aff_in, const
       });
     }
     static const bool no_pair = [] { const char* e = getenv("SRCFD_NO_PAIR"); return e && atoi(e) != 0; }();
+    static const bool no_triple = [] { const char* e = getenv("SRCFD_NO_TRIPLE"); return e && atoi(e) != 0; }();
+    if (!naive && !no_pair && !no_triple && (int)i == triple_op && i + 3 < ops.size()) {  // ConvT#2 -> #3 -> #4 in one kernel
+      TripleDesc td;
+      td.n = n; td.H = d.MH; td.W = d.MW; td.act1 = d.act; td.act2 = ops[i + 1].d.act; td.act3 = ops[i + 2].d.act;
+      const std::string nm = op.name + "+" + ops[i + 1].name + "+" + ops[i + 2].name;
+      rc = launch(nm.c_str(), s, [&] {
+        return launch_convt_triple_f32(td, X, d_pack + tri_w1, d_pack + tri_b1, d_pack + tri_w2, d_pack + tri_b2, d_pack + tri_w3,
+                                       d_pack + tri_b3, Y, s);
+      });
+      if (rc) return rc;
+      prev_layer = ops[i + 2].layer;
+      i += 2;
+      continue;
+    }
     if (!naive && !no_pair && (int)i == pair_op && i + 2 < ops.size()) {  // ConvT#3 -> ConvT#4 in one kernel (kernels.h, PairDesc)
       PairDesc pd;
       pd.n = n; pd.H = d.MH; pd.W = d.MW; pd.act_a = d.act; pd.act_b = ops[i + 1].d.act;
@@ -434,6 +488,7 @@ static int finish_create(std::unique_ptr<Model>& m, srcfd_model** out) {
     m->desc.infer_shapes();
     build_plan(m->desc, m->ops, m->pack);
     plan_convt_pair(*m);
+    plan_convt_triple(*m);
   } catch (const std::exception& e) {
     set_error(e.what());
     return SRCFD_EINVAL;

@@ -54,6 +54,14 @@ struct PairDesc {
 // wa [2 tiles][16 k-steps][64 lanes], ba [16], wb [8 k-steps][64 lanes], bb [8]: see pack_convt_pair() in engine.hip
 hipError_t launch_convt_pair_f32(const PairDesc& d, const float* X, const float* wa, const float* ba, const float* wb, const float* bb,
                                  float* Y, hipStream_t s);
+// The same with one more layer in front: 64 -> 32 -> 16 -> 8 channels (ConvT#2 -> ConvT#3 -> ConvT#4), input (n, H, W, 64),
+// output (n, 8H, 8W, 8).  w1 [4 tiles][32 k-steps][64 lanes] (staged in LDS), b1 [32]; w2 [2][16][64], b2 [16]; w3 [8][64], b3 [8].
+struct TripleDesc {
+  int n, H, W;
+  int act1, act2, act3;
+};
+hipError_t launch_convt_triple_f32(const TripleDesc& d, const float* X, const float* w1, const float* b1, const float* w2, const float* b2,
+                                   const float* w3, const float* b3, float* Y, hipStream_t s);
 // Last layer + de-standardise + NaN guard + output cast in one kernel, for the layers gemm_fuses_finalize() accepts.
 bool gemm_fuses_finalize(const GemmDesc& d);
 hipError_t launch_gemm_finalize(const GemmDesc& d, const float* X, const float* B, const float* bias, void* out, int out_dtype,
