@@ -885,19 +885,21 @@ hipError_t launch_convt_pair_f32(const PairDesc& d, const float* X, const float*
 // A tile of the first GEMM is exactly one tap (32 channels = 32 rows), so accA[tap1] feeds the second GEMM whole
 // (k-step u contracts channels (u&3) + 8(u>>2) + 4h); the first GEMM is done one tap and the second one 32-row tile (= ty2)
 // at a time, so that 16 accumulators of each are live (all 64 first-layer accumulators at once spilled to scratch and
-// left one wave per SIMD: 0.73 ms per 256 samples).  First-layer weights (32 KB) are shared by the workgroup's waves through LDS;
-// the other two layers' 40 A-operand registers stay resident.  Each input pixel becomes an 8 x 8 output block; rows leave
-// through the same wave-private staging tile as in the pair kernel (128-byte segments: 4 output pixels x 32 B).
+// left one wave per SIMD: 0.73 ms per 256 samples).  A workgroup takes one 32-pixel group and its four waves one first-layer
+// tap each (the taps are independent all the way down), so a wave holds one tile of the first layer's weights (32 registers)
+// next to the other two layers' 40, and a single field (235 groups) still spreads over 940 waves.  Each input pixel
+// becomes an 8 x 8 output block; rows leave through the same wave-private staging tile as in the pair kernel (128-byte segments: 4 output pixels x 32 B).
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) convt_triple_f32(TripleDesc d, const float* __restrict__ X, const float* __restrict__ w1,
                                                          const float* __restrict__ b1, const float* __restrict__ w2,
                                                          const float* __restrict__ b2, const float* __restrict__ w3,
                                                          const float* __restrict__ b3, float* __restrict__ Y) {
-  __shared__ float w1s[4 * 32 * 64];
   __shared__ __attribute__((aligned(16))) char tri_stage[4][2 * 32 * PAIR_PITCH];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, h = lane >> 5, l31 = lane & 31;
-  for (int i = threadIdx.x; i < 4 * 32 * 64 / 4; i += 256) reinterpret_cast<float4*>(w1s)[i] = reinterpret_cast<const float4*>(w1)[i];
-  float wB[2][16], wC[8], bA[16], bB[8], bC[4];
+  // work item = (pixel group, first-layer tap) with tap == wave index (below), so a wave needs one tile of w1 only: 32 registers
+  float wA[32], wB[2][16], wC[8], bA[16], bB[8], bC[4];
+#pragma unroll
+  for (int s = 0; s < 32; ++s) wA[s] = w1[((size_t)wave * 32 + s) * 64 + lane];
 #pragma unroll
   for (int T = 0; T < 2; ++T)
 #pragma unroll
@@ -910,11 +912,13 @@ __global__ void __launch_bounds__(256) convt_triple_f32(TripleDesc d, const floa
   for (int r = 0; r < 8; ++r) bB[r] = b2[(r & 3) + 4 * h + 8 * (r >> 2)];
 #pragma unroll
   for (int r = 0; r < 4; ++r) bC[r] = b3[r + 4 * h];
-  __syncthreads();
   char* stage = tri_stage[wave];
   const int64_t M = (int64_t)d.n * d.H * d.W, groups = (M + 31) / 32;
   const int OH = 8 * d.H, OW = 8 * d.W;
-  for (int64_t g = (int64_t)blockIdx.x * 4 + wave; g < groups; g += (int64_t)gridDim.x * 4) {
+  // one work item = (32-pixel group, first-layer tap): the four taps of a group are independent all the way down, so they go
+  // to different waves -- a quarter of the serial chain per item (a single field is only 235 groups), input re-read from L2
+  const int tap1 = wave;
+  for (int64_t g = blockIdx.x; g < groups; g += gridDim.x) {
     const int64_t m = g * 32 + l31;
     const bool ok = m < M;
     const int64_t mm = ok ? m : M - 1;
@@ -925,16 +929,14 @@ __global__ void __launch_bounds__(256) convt_triple_f32(TripleDesc d, const floa
     const int img = (int)(mm / ((int64_t)d.H * d.W));
     const int rem = (int)(mm - (int64_t)img * d.H * d.W), y = rem / d.W, x = rem - y * d.W;
     const int64_t obase = ok ? (((int64_t)img * OH + 8 * y) * OW + 8 * x) * 8 : -1;
-#pragma unroll 1
-    for (int tap1 = 0; tap1 < 4; ++tap1) {
+    {
       const int ty1 = tap1 >> 1, tx1 = tap1 & 1;
       // first layer, one tap (= one 32-row tile) at a time: 16 live accumulators instead of 64
       f32x16 accA;
 #pragma unroll
       for (int r = 0; r < 16; ++r) accA[r] = bA[r];
-      const float* wt = w1s + tap1 * (32 * 64) + lane;
 #pragma unroll
-      for (int s = 0; s < 32; ++s) accA = __builtin_amdgcn_mfma_f32_32x32x2f32(wt[s * 64], xs[s], accA, 0, 0, 0);
+      for (int s = 0; s < 32; ++s) accA = __builtin_amdgcn_mfma_f32_32x32x2f32(wA[s], xs[s], accA, 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 16; ++r) accA[r] = act_apply_precise(accA[r], d.act1);
 #pragma unroll
@@ -980,7 +982,7 @@ hipError_t launch_convt_triple_f32(const TripleDesc& d, const float* X, const fl
   const int64_t M = (int64_t)d.n * d.H * d.W;
   if (M == 0) return hipSuccess;
   const int64_t groups = (M + 31) / 32;
-  const int blocks = (int)std::min<int64_t>((groups + 3) / 4, 256 * 2);  // LDS: two workgroups per CU
+  const int blocks = (int)std::min<int64_t>(groups, 256 * 2);  // one workgroup per pixel group at a time (wave = tap); two resident per CU
   hipLaunchKernelGGL(convt_triple_f32, dim3(blocks), dim3(256), 0, s, d, X, w1, b1, w2, b2, w3, b3, Y);
   return hipGetLastError();
 }
