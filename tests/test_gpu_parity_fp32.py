@@ -308,3 +308,43 @@ def test_full_model_with_far_out_of_range_inputs(srcfd, oracle, enc_weights, dec
         y = m.predict(x)
         assert np.isfinite(y).all(), prec
         assert oracle.rel_l2(y, ref) <= tol, (prec, oracle.rel_l2(y, ref))
+
+
+@pytest.mark.parametrize("chain", [(64, 32, 16, 8), (32, 16, 8)], ids=["triple_64_32_16_8", "pair_32_16_8"])
+def test_chained_transposed_convolutions(srcfd, oracle, chain, monkeypatch):
+    """The kernel = stride = 2 transposed-convolution chains that run as ONE kernel (convt_triple_f32 / convt_pair_f32):
+    odd image sizes (pixel groups of 32 straddle rows and samples, the last group is partial), mixed activations, against
+    the float64 oracle -- and against the layer-by-layer launches of the same model."""
+    require_gpu(srcfd)
+    rng = np.random.default_rng(len(chain))
+    h, w, n = 5, 7, 3
+    acts = ["swish", "swish", "linear"][-(len(chain) - 1):] if len(chain) == 4 else ["swish", "swish"]
+    specs, ws = [], []
+    for i in range(len(chain) - 1):
+        cin, cout = chain[i], chain[i + 1]
+        wt = rng.standard_normal((2, 2, cout, cin)).astype(np.float32) / np.sqrt(cin)
+        b = rng.standard_normal(cout).astype(np.float32) * 0.1
+        ws.append((wt, b, acts[i]))
+        specs.append(dict(kind="conv2d_transpose", k=2, stride=2, same=False, act=acts[i], w=wt, b=b))
+    wo = rng.standard_normal((3, 3, 8, 1)).astype(np.float32) / np.sqrt(72)
+    bo = rng.standard_normal(1).astype(np.float32) * 0.1
+    specs.append(dict(kind="conv2d", k=3, stride=1, same=True, act="linear", w=wo, b=bo))   # the chain must not be last
+    x = rng.standard_normal((n, h, w, chain[0])).astype(np.float32)
+    ref = x.astype(np.float64)
+    for wt, b, a in ws:
+        ref = oracle.conv2d_transpose(ref, wt, b, 2, "valid", a)
+    ref = oracle.conv2d(ref, wo, bo, 1, "same", "linear")
+    m = srcfd.SRModel.from_layers(specs, (h, w, chain[0]), device=0)
+    y = m.predict(x)
+    assert y.shape == ref.shape and oracle.rel_l2(y, ref) <= TOL_FP32
+    m.set_profiling(True)                                    # the fused kernel really is what ran: one launch named a+b(+c)
+    m.predict(x)
+    names = [nm for nm, _ in m.get_profile()]
+    m.set_profiling(False)
+    assert sum("+" in nm for nm in names) == 1 and max(nm.count("+") for nm in names) == len(chain) - 2, names
+    m.precision = "fp32_naive"
+    assert oracle.rel_l2(m.predict(x), ref) <= TOL_FP32
+    # a batch that is not the first in its buffer: rows of a bigger batch equal the small batch's (per-pixel independence)
+    m.precision = "fp32"
+    big = np.concatenate([x, rng.standard_normal((5, h, w, chain[0])).astype(np.float32)])
+    np.testing.assert_array_equal(m.predict(big)[:n], y)
