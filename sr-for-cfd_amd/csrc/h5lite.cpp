@@ -35,12 +35,26 @@ const Attr* Node::attr(const std::string& name) const {
 
 [[noreturn]] static void fail(const std::string& m) { throw std::runtime_error("h5lite: " + m); }
 
+// product of the dimensions times `elem`, refusing anything that wraps in 64 bits (a crafted file can carry dims whose
+// product wraps to a small number: every size check downstream would then see the wrapped value)
+static uint64_t checked_bytes(const std::vector<uint64_t>& dims, uint64_t elem, uint64_t* count = nullptr) {
+  uint64_t n = 1;
+  for (auto d : dims)
+    if (__builtin_mul_overflow(n, d, &n)) fail("dataspace too large");
+  uint64_t bytes = 0;
+  if (__builtin_mul_overflow(n, elem, &bytes)) fail("dataspace too large");
+  if (count) *count = n;
+  return bytes;
+}
+
 // ---------------------------------------------------------------------------
 // reader
 // ---------------------------------------------------------------------------
 struct Parser {
   const std::vector<uint8_t>& b;
   int so = 8, sl = 8;  // size of offsets / lengths
+  int budget = 200000;  // objects + B-tree nodes + heap entries visited: a cyclic or self-similar file cannot loop for ever
+  void spend() { if (--budget < 0) fail("file structure too large or cyclic"); }
   explicit Parser(const std::vector<uint8_t>& buf) : b(buf) {}
 
   void need(uint64_t off, uint64_t n) const {
@@ -93,6 +107,7 @@ struct Parser {
     else if (ver == 2) q = p + 4;
     else fail("dataspace version " + std::to_string(ver));
     dims.clear();
+    if (rank > 32) fail("dataspace rank " + std::to_string(rank));
     for (int i = 0; i < rank; ++i) dims.push_back(u(q + (uint64_t)i * sl, sl));
     scalar = (rank == 0);
   }
@@ -105,16 +120,20 @@ struct Parser {
     need(col, 16);
     if (std::memcmp(&b[col], "GCOL", 4)) fail("bad global heap signature");
     uint64_t csize = u(col + 8, sl);
+    need(col, csize);  // the whole collection lies inside the file, so `end` cannot wrap
     uint64_t q = col + 8 + sl, end = col + csize;
     while (q + 8 + sl <= end) {
+      const_cast<Parser*>(this)->spend();
       uint32_t oidx = (uint32_t)u(q, 2);
       uint64_t osize = u(q + 8, sl);
       if (oidx == idx) {
+        if (len > osize) fail("vlen string longer than its heap object");
         need(q + 8 + sl, len);
         return std::string((const char*)&b[q + 8 + sl], len);
       }
       if (oidx == 0) break;
-      q += 8 + sl + ((osize + 7) & ~7ull);
+      if (osize > end - q) fail("global heap object runs past its collection");  // also keeps the padded step from wrapping
+      q += 8 + sl + ((osize + 7) & ~7ull);  // always > q: forward progress
     }
     fail("global heap object not found");
   }
@@ -133,9 +152,10 @@ struct Parser {
     TypeInfo ti = parse_type(tp);
     parse_space(sp, a.scalar, a.dims);
     uint64_t n = 1;
-    for (auto d : a.dims) n *= d;
+    const uint64_t abytes = checked_bytes(a.dims, ti.t == STR ? (ti.vlen_str ? 8u + so : std::max<uint32_t>(ti.size, 1)) : std::max<uint32_t>(ti.size, 1), &n);
     a.dtype = ti.t;
     a.utf8 = ti.utf8;
+    if (ti.t != UNKNOWN) need(q, abytes);  // payload bounds before any per-element loop
     if (ti.t == STR) {
       for (uint64_t i = 0; i < n; ++i) {
         if (ti.vlen_str) a.strings.push_back(gheap_string(q + i * (8 + so)));
@@ -165,6 +185,7 @@ struct Parser {
 
   void walk_btree(uint64_t bt, uint64_t heap_data, Node& g, int depth) {
     if (depth > 64) fail("b-tree too deep");
+    spend();
     need(bt, 8);
     if (std::memcmp(&b[bt], "TREE", 4)) fail("bad B-tree signature");
     int level = (int)u(bt + 5, 1), used = (int)u(bt + 6, 2);
@@ -179,9 +200,13 @@ struct Parser {
         for (int s = 0; s < ns; ++s) {
           uint64_t e = child + 8 + (uint64_t)s * (2 * so + 24);
           uint64_t noff = u(e, so), oh = off_at(e + so);
-          uint64_t np = heap_data + noff;
+          uint64_t np = 0;
+          if (__builtin_add_overflow(heap_data, noff, &np)) fail("link name offset");
           need(np, 1);
-          std::string name((const char*)&b[np]);
+          // NUL-terminated inside the file buffer, never an unbounded strlen past its end
+          const void* z = std::memchr(&b[np], 0, b.size() - np);
+          if (!z) fail("unterminated link name");
+          std::string name((const char*)&b[np], (const char*)z - (const char*)&b[np]);
           g.children.emplace_back(name, parse_object(oh, depth + 1));
         }
       }
@@ -190,6 +215,7 @@ struct Parser {
 
   std::shared_ptr<Node> parse_object(uint64_t oh, int depth) {
     if (depth > 64) fail("group nesting too deep");
+    spend();
     auto node = std::make_shared<Node>();
     need(oh, 16);
     int ver = (int)u(oh, 1);
@@ -254,10 +280,13 @@ struct Parser {
     }
     node->is_group = have_symtab || have_links || !have_layout;
     if (!node->is_group) {
-      uint64_t n = 1;
-      for (auto dd : node->dims) n *= dd;
       if (ti.t == UNKNOWN || ti.t == STR) node->dtype = UNKNOWN;
-      else if (node->data_addr != UNDEF && n) need(node->data_addr, n * ti.size);
+      else {
+        // every later read copies dims x element size bytes: the storage the layout message names must hold them
+        const uint64_t bytes = checked_bytes(node->dims, ti.size);
+        if (node->data_addr != UNDEF) need(node->data_addr, bytes);
+        else if (bytes > node->data.size()) fail("dataset storage smaller than its dataspace (compact or unallocated layout)");
+      }
     }
     return node;
   }
@@ -310,12 +339,15 @@ static void conv(const uint8_t* src, void* dst, uint64_t n) {
 
 void File::read(Node* ds, void* dst, size_t dst_bytes, DType as) {
   if (!ds || ds->is_group) fail("read: not a dataset");
-  uint64_t n = 1;
-  for (auto d : ds->dims) n *= d;
   size_t ssz = dtype_size(ds->dtype), dsz = dtype_size(as);
   if (!ssz || !dsz) fail("read: unsupported dtype");
-  if (dst_bytes < n * dsz) fail("read: destination too small");
-  const uint8_t* src = ds->data_addr == UNDEF || buf_.empty() ? ds->data.data() : buf_.data() + ds->data_addr;
+  uint64_t n = 1;
+  const uint64_t sbytes = checked_bytes(ds->dims, ssz, &n), dbytes = checked_bytes(ds->dims, dsz);
+  if (dst_bytes < dbytes) fail("read: destination too small");
+  const bool in_file = ds->data_addr != UNDEF && !buf_.empty();
+  if (in_file ? (ds->data_addr > buf_.size() || sbytes > buf_.size() - ds->data_addr) : sbytes > ds->data.size())
+    fail("read: dataset storage smaller than its dataspace");
+  const uint8_t* src = in_file ? buf_.data() + ds->data_addr : ds->data.data();
   if (ds->dtype == as) { std::memcpy(dst, src, n * ssz); return; }
 #define CV(S, ST, D, DT) if (ds->dtype == S && as == D) { conv<ST, DT>(src, dst, n); return; }
   CV(F32, float, F64, double) CV(F64, double, F32, float)

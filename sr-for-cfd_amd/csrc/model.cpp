@@ -227,7 +227,8 @@ void append_h5_submodel(ModelDesc& m, const std::string& path) {
           }
           if (!ds || ds->is_group) throw std::runtime_error("dataset for weight '" + wn->strings[wi] + "' missing");
           uint64_t cnt = 1;
-          for (auto d : ds->dims) cnt *= d;
+          for (auto d : ds->dims)
+            if (__builtin_mul_overflow(cnt, d, &cnt) || cnt > (1ull << 28)) throw std::runtime_error("weight '" + wn->strings[wi] + "' is implausibly large");
           std::vector<float>& dst = wi == 0 ? L.kernel : L.bias;
           dst.resize(cnt);
           file->read(ds, dst.data(), cnt * sizeof(float), h5lite::F32);

@@ -107,3 +107,61 @@ def test_tiled_sr_sharded_over_three_ranks():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert [g[1] for g in got] == [16, 16, 16] and all(g[2] for g in got)
+
+
+def _run_bench(argv, env_extra, timeout=600):
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.update(env_extra)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=timeout)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{"metric"')]
+    return p.returncode, [json.loads(ln) for ln in lines], p.stderr
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE must itself start two ranks (children, before any GPU call) and print ONE line
+    with n_gpus = 2 = the world size the process group reports.  Rank plumbing only: SRCFD_BENCH_DRYRUN."""
+    rc, recs, err = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1"], {"SRCFD_BENCH_DRYRUN": "1"})
+    assert rc == 0, err
+    assert len(recs) == 1
+    r = recs[0]
+    assert r["n_gpus"] == 2 and r["world_size_reported"] == 2 and r["dry_run"] is True and r["value"] is None
+    assert r["max_over_ranks"] == 2.0 and r["tile_samples_covered"] == 48
+    assert r["env"] == {"SRCFD_BENCH_DRYRUN": "1"}          # every SRCFD_* variable is recorded in the line
+
+
+def test_bench_refuses_mismatched_world_and_diagnostic_switches():
+    rc, recs, err = _run_bench(["--gpus", "4"], {"SRCFD_BENCH_DRYRUN": "1", "WORLD_SIZE": "2", "RANK": "0"})
+    assert rc != 0 and not recs and "WORLD_SIZE=2" in err
+    for var in ("SRCFD_TAIL_ABLATE", "SRCFD_MID_ABLATE", "SRCFD_TAIL_PROF"):
+        rc, recs, err = _run_bench([], {var: "1"})
+        assert rc != 0 and not recs and var in err
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_one_gpu():
+    """The full rank path of bench.py (`--gpus 2` -> two child ranks, barrier, MAX over ranks, aggregate) on ONE GPU with the
+    gloo backend standing in for RCCL; 8 fields per rank.  n_gpus and the aggregate must reflect both ranks."""
+    rc, recs, err = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--fields", "8", "--no-cpu-baseline"],
+                               {"SRCFD_BENCH_BACKEND": "gloo"}, timeout=900)
+    assert rc == 0, err[-2000:]
+    r = recs[0]
+    assert r["n_gpus"] == 2 and r["world_size_reported"] == 2
+    assert r["value"] == pytest.approx(2 * 8 / (r["ms_per_step"] * 1e-3), rel=1e-3)
+    assert r["nonfinite"] == 0 and r["roofline"]["frac"] > 0
+    assert r["parity_path"]["roofline"]["avg_launch_ms"] <= r["parity_path"]["ms_per_step"] * 1.02
+    assert r["train"]["global_batch"] == 16 and r["train"]["loss_finite"]
+    assert r["tiled"]["tile_samples"] == 48
+
+
+@pytest.mark.gpu
+def test_bench_needs_as_many_devices_as_ranks():
+    import torch
+    n = torch.cuda.device_count()
+    rc, recs, err = _run_bench(["--gpus", str(n + 1), "--steps", "1", "--warmup", "0", "--no-extras", "--no-cpu-baseline"], {}, timeout=600)
+    assert rc != 0 and not recs

@@ -222,20 +222,25 @@ def test_coarse_field_files(srcfd, coarse_cases):
     assert abs(v.max() + v.min()) < 1e-6  # double-lid symmetry noted in SURVEY.md section 4
 
 
-def test_corrupted_weight_files_raise_and_never_crash(tmp_path):
-    """Structure-aware byte mutations of the real encoder .h5 (B-tree / heap / symbol-table nodes, truncation): the loader
-    must answer with an exception (OSError / ValueError / KeyError ...) or load, never crash or hang.  Runs in a child
-    process so that a crash would be a test failure rather than the end of the session.  (The same harness built with
-    -fsanitize=address,undefined passed 1900 mutations.)"""
+def _mutation_corpus(tmp_path, n_random=120):
+    """Structure-aware mutations of the real encoder .h5: random bytes / all-ones / huge 8-byte values near every B-tree,
+    symbol-table, heap and superblock signature, truncations, and targeted ones for the parser's size arithmetic:
+    dataspace dimensions whose product (or product x element size) wraps 64 bits, contiguous layouts flipped to compact
+    or given an undefined address, link names with their terminator removed up to the end of the file, and global-heap
+    object sizes that stall or overrun the heap walk."""
     import re
-    import subprocess
-    import sys
     data = bytearray(open(ENCODER_H5, "rb").read())
+    n = len(data)
     sigs = [m.start() for m in re.finditer(b"TREE|SNOD|HEAP|GCOL|\x89HDF", bytes(data))]
     rng = np.random.default_rng(99)
-    n = len(data)
-    paths = []
-    for it in range(120):
+    out = []
+
+    def emit(d, tag):
+        p = tmp_path / f"m{len(out)}_{tag}.h5"
+        p.write_bytes(bytes(d))
+        out.append(str(p))
+
+    for it in range(n_random):
         d = bytearray(data)
         for _ in range(int(rng.integers(1, 5))):
             pos = min(n - 9, int(sigs[int(rng.integers(0, len(sigs)))]) + int(rng.integers(0, 256)))
@@ -248,9 +253,48 @@ def test_corrupted_weight_files_raise_and_never_crash(tmp_path):
                 d[pos:pos + 8] = [2**64 - 1, 2**63 - 1, n + 12345, 1 << 40][int(rng.integers(0, 4))].to_bytes(8, "little")
         if rng.random() < 0.1:
             d = d[: int(rng.integers(100, n))]
-        p = tmp_path / f"m{it}.h5"
-        p.write_bytes(bytes(d))
-        paths.append(str(p))
+        emit(d, "rand")
+    # dataspace messages (version 1: 01 rank flags 00 00 00 00 00, then rank x 8-byte dims) of the weight datasets
+    spaces = [m.start() for m in re.finditer(b"\x01[\x01-\x04]\x00\x00\x00\x00\x00\x00", bytes(data))]
+    wraps = [(1 << 62) + 1, (1 << 63) + 3, (1 << 64) - 1, 1 << 61, (1 << 32) + 1]
+    for pos in spaces[:40]:
+        rank = data[pos + 1]
+        for w in wraps[:3]:
+            d = bytearray(data)
+            d[pos + 8:pos + 16] = w.to_bytes(8, "little")
+            if rank > 1:
+                d[pos + 16:pos + 24] = wraps[3].to_bytes(8, "little")
+            emit(d, "dims")
+    # layout messages, version 3 class 1 (contiguous): 03 01 <addr 8> <size 8>
+    layouts = [m.start() for m in re.finditer(b"\x03\x01", bytes(data)) if m.start() + 18 < n and
+               int.from_bytes(data[m.start() + 2:m.start() + 10], "little") < n and
+               0 < int.from_bytes(data[m.start() + 10:m.start() + 18], "little") < n]
+    for pos in layouts[:30]:
+        d = bytearray(data); d[pos + 1] = 0; d[pos + 2:pos + 4] = (4).to_bytes(2, "little"); emit(d, "compact")   # 4 bytes of compact data
+        d = bytearray(data); d[pos + 2:pos + 10] = b"\xff" * 8; emit(d, "undef_addr")                              # no storage at all
+    # names in local heaps: no terminator between a name and the end of the (truncated) file
+    for pos in [m.start() for m in re.finditer(b"HEAP", bytes(data))][:10]:
+        seg = int.from_bytes(data[pos + 24:pos + 32], "little")                # data segment address
+        if 0 < seg < n - 64:
+            d = bytearray(data[:min(n, seg + 48)])
+            for i in range(seg, len(d)):
+                if d[i] == 0:
+                    d[i] = 0x41
+            emit(d, "name")
+    # global heap collections: object sizes of ~2^64 (the padded step wraps to 0: no forward progress) and past the collection
+    for pos in [m.start() for m in re.finditer(b"GCOL", bytes(data))][:6]:
+        for val in ((1 << 64) - 8, (1 << 64) - 24, 1 << 40):
+            d = bytearray(data); d[pos + 24:pos + 32] = val.to_bytes(8, "little"); emit(d, "gheap")      # first object's size
+        d = bytearray(data); d[pos + 8:pos + 16] = ((1 << 64) - 1).to_bytes(8, "little"); emit(d, "gcol_size")
+    return out
+
+
+def test_corrupted_weight_files_raise_and_never_crash(tmp_path):
+    """The loader must answer every mutated file with an exception (OSError / ValueError / KeyError ...) or load it, never
+    crash or hang.  Runs in a child process so that a crash would be a test failure rather than the end of the session."""
+    import subprocess
+    import sys
+    paths = _mutation_corpus(tmp_path)
     code = (
         "import sys, importlib\n"
         f"sys.path.insert(0, {ROOT!r})\n"
@@ -261,8 +305,36 @@ def test_corrupted_weight_files_raise_and_never_crash(tmp_path):
         "        m = srcfd.SRModel.load_h5(p, None, device=-1); m.weights(); ok += 1\n"
         "    except Exception:\n"
         "        bad += 1\n"
+        "    try:\n"
+        "        f = srcfd.H5File(p)\n"
+        "        for name in ('model_weights/dense/dense/kernel', 'model_weights/conv2d/conv2d/bias'):\n"
+        "            f.read(name)\n"
+        "    except Exception:\n"
+        "        pass\n"
         "print(ok, bad)\n")
-    out = subprocess.run([sys.executable, "-c", code] + paths, capture_output=True, text=True, timeout=300)
+    out = subprocess.run([sys.executable, "-c", code] + paths, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     ok, bad = map(int, out.stdout.split())
     assert ok + bad == len(paths) and bad > 0
+
+
+def test_corrupted_weight_files_under_address_sanitizer(tmp_path):
+    """The same corpus through the host-only AddressSanitizer + UBSan build of h5lite.cpp / model.cpp / capi_io.cpp
+    (`make -C sr-for-cfd_amd/csrc asan`, harness tools/h5_check.cpp): a silent over-read that an ordinary build survives
+    ends this process with a sanitizer report (sanitizers run on the CPU build only)."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no host compiler")
+    csrc = os.path.join(ROOT, "sr-for-cfd_amd", "csrc")
+    subprocess.check_call(["make", "-C", csrc, "asan"], stdout=subprocess.DEVNULL)
+    exe = os.path.join(ROOT, "sr-for-cfd_amd", "lib", "h5_check_asan")
+    clean = subprocess.run([exe, ENCODER_H5], capture_output=True, text=True, timeout=120)
+    assert clean.returncode == 0 and clean.stdout.split()[:2] == ["1", "0"], clean.stderr[-2000:]
+    paths = _mutation_corpus(tmp_path, n_random=300)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:allocator_may_return_null=1", UBSAN_OPTIONS="print_stacktrace=1")
+    for lo in range(0, len(paths), 100):
+        out = subprocess.run([exe] + paths[lo:lo + 100], capture_output=True, text=True, timeout=600, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        ok, bad, _ = map(int, out.stdout.split())
+        assert ok + bad == len(paths[lo:lo + 100])
