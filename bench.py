@@ -433,7 +433,7 @@ def main():
     args = parse_args(argv)
     env = srcfd_env()
     bad_env = [k for k in env if k in REFUSED_ENV and env[k] not in ("", "0")]
-    if bad_env:
+    if bad_env and os.environ.get("SRCFD_BENCH_ALLOW_DIAG", "0") in ("", "0"):
         raise SystemExit(f"bench.py: diagnostic switches {bad_env} are set: they skip work or add synchronisation; refusing to report a number")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args, argv))
@@ -506,6 +506,8 @@ def main():
             "parity_path": parity, "train": train, "tiled": tiled, "host_io": host_io,
             "env": env,
         }
+        if bad_env:
+            out["INVALID_diagnostic_run"] = bad_env   # SRCFD_BENCH_ALLOW_DIAG=1 with a DIAG=1 build: tools/ablate*.sh only
         print(json.dumps(out))
     if job.world > 1:
         job.dist.destroy_process_group()

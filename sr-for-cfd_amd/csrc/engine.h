@@ -46,6 +46,11 @@ struct Model {
   // ops[triple_op .. +2]: the same with a 64 -> 32 layer in front (kernels.h, TripleDesc); takes precedence over the pair
   int triple_op = -1;
   size_t tri_w1 = 0, tri_b1 = 0, tri_w2 = 0, tri_b2 = 0, tri_w3 = 0, tri_b3 = 0;
+  // ops[tail32_op .. +3]: that chain followed by the network's last layer, a 3x3 SAME conv 8 -> 1 (kernels.h, Tail32Params):
+  // one streaming kernel; takes precedence over the triple
+  int tail32_op = -1;
+  size_t t32_w1 = 0, t32_b1 = 0, t32_w2 = 0, t32_b2 = 0, t32_w3 = 0, t32_b3 = 0, t32_wc = 0;
+  int num_cus = 256;
   float* d_pack = nullptr;
 
   float* buf[2] = {nullptr, nullptr};

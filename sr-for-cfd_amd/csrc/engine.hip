@@ -197,6 +197,57 @@ static void plan_convt_triple(Model& m) {
   }
 }
 
+// Operands of the fused f32 tail (kernels_tail32.hip): the ConvT 64 -> 32 -> 16 -> 8 chain + the 3x3 SAME conv 8 -> 1 that
+// ends the network, v_mfma_f32_16x16x4_f32 fragments (lane = (m = lane & 15, kg = lane >> 4)):
+//   w1[((tap1*2 + t)*16 + s)*64 + lane] = W1[tap1][co 16t + m][ci 16kg + s]
+//   w2[(tap2*8 + 4t + i)*64 + lane]     = W2[tap2][co m][ci 16t + 4kg + i]      (k order = the first layer's accumulator order)
+//   w3[(u*4 + i)*64 + lane]             = W3[tap3 2u + (m >> 3)][co m & 7][ci 4kg + i]
+// Conv2DTranspose kernels are (kh, kw, Cout, Cin); the Conv2D kernel (3, 3, 8, 1) is already (ty, tx, ci).
+static void plan_tail32(Model& m) {
+  m.tail32_op = -1;
+  if (m.triple_op < 0 || (size_t)m.triple_op + 4 != m.ops.size()) return;
+  const size_t i = (size_t)m.triple_op;
+  const Op& last = m.ops[i + 3];
+  if (last.layer != m.ops[i + 2].layer + 1) return;
+  const Layer &L1 = m.desc.layers[m.ops[i].layer], &L2 = m.desc.layers[m.ops[i + 1].layer], &L3 = m.desc.layers[m.ops[i + 2].layer];
+  const Layer& LO = m.desc.layers[last.layer];
+  if (LO.kind != SRCFD_LAYER_CONV2D || LO.kh != 3 || LO.kw != 3 || LO.stride != 1 || !LO.same || LO.cin != 8 || LO.cout != 1) return;
+  if (m.ops[i].d.MW > 50) return;  // the LDS ring holds rows of up to 400 pixels
+  for (const Layer* L : {&L1, &L2, &L3, &LO})
+    if (L->act != SRCFD_ACT_SWISH && L->act != SRCFD_ACT_LINEAR) return;
+  auto& pk = m.pack;
+  auto align = [&]() { while (pk.size() % 64) pk.push_back(0.f); };
+  align(); m.t32_w1 = pk.size(); pk.resize(pk.size() + 4 * 2 * 16 * 64);
+  for (int tap = 0; tap < 4; ++tap)
+    for (int t = 0; t < 2; ++t)
+      for (int s = 0; s < 16; ++s)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int mm = lane & 15, kg = lane >> 4;
+          pk[m.t32_w1 + (size_t)((tap * 2 + t) * 16 + s) * 64 + lane] = L1.kernel[((size_t)tap * 32 + 16 * t + mm) * 64 + 16 * kg + s];
+        }
+  align(); m.t32_b1 = pk.size(); pk.insert(pk.end(), L1.bias.begin(), L1.bias.end());
+  align(); m.t32_w2 = pk.size(); pk.resize(pk.size() + 4 * 8 * 64);
+  for (int tap = 0; tap < 4; ++tap)
+    for (int t = 0; t < 2; ++t)
+      for (int ii = 0; ii < 4; ++ii)
+        for (int lane = 0; lane < 64; ++lane) {
+          const int mm = lane & 15, kg = lane >> 4;
+          pk[m.t32_w2 + (size_t)(tap * 8 + 4 * t + ii) * 64 + lane] = L2.kernel[((size_t)tap * 16 + mm) * 32 + 16 * t + 4 * kg + ii];
+        }
+  align(); m.t32_b2 = pk.size(); pk.insert(pk.end(), L2.bias.begin(), L2.bias.end());
+  align(); m.t32_w3 = pk.size(); pk.resize(pk.size() + 2 * 4 * 64);
+  for (int u = 0; u < 2; ++u)
+    for (int ii = 0; ii < 4; ++ii)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int mm = lane & 15, kg = lane >> 4;
+        pk[m.t32_w3 + (size_t)(u * 4 + ii) * 64 + lane] = L3.kernel[((size_t)(2 * u + (mm >> 3)) * 8 + (mm & 7)) * 16 + 4 * kg + ii];
+      }
+  align(); m.t32_b3 = pk.size(); pk.insert(pk.end(), L3.bias.begin(), L3.bias.end());
+  align(); m.t32_wc = pk.size(); pk.insert(pk.end(), LO.kernel.begin(), LO.kernel.end()); pk.push_back(LO.bias[0]);
+  align();
+  m.tail32_op = (int)i;
+}
+
 // ---------------------------------------------------------------------------
 // model
 // ---------------------------------------------------------------------------
@@ -235,6 +286,7 @@ int Model::init_device() {
   }
   if (device >= cnt) { set_error("device index out of range"); return SRCFD_EINVAL; }
   HIPCHECK(hipSetDevice(device));
+  { hipDeviceProp_t prop; HIPCHECK(hipGetDeviceProperties(&prop, device)); num_cus = prop.multiProcessorCount; }
   HIPCHECK(hipMalloc(&d_pack, pack.size() * sizeof(float)));
   HIPCHECK(hipMemcpy(d_pack, pack.data(), pack.size() * sizeof(float), hipMemcpyHostToDevice));
   return SRCFD_OK;
@@ -320,6 +372,18 @@ int Model::forward_generic(const float* x_dev, int n, const float* aff_in, const
       return launch(op.name.c_str(), s, [&] {
         return launch_gemm_finalize(d, X, B, bias, y_dev, out_dtype, aff_out, flags & SRCFD_FLAG_NAN_GUARD, nonfinite, s);
       });
+    }
+    static const bool no_tail32 = [] { const char* e = getenv("SRCFD_NO_TAIL32"); return e && atoi(e) != 0; }();
+    if (!naive && !no_tail32 && (int)i == tail32_op) {  // ConvT#2 -> #3 -> #4 -> output conv + finalize: one streaming kernel
+      Tail32Params tp;
+      tp.in = X; tp.out = y_dev; tp.n = n; tp.H = d.MH; tp.W = d.MW;
+      tp.w1f = d_pack + t32_w1; tp.b1 = d_pack + t32_b1; tp.w2f = d_pack + t32_w2; tp.b2 = d_pack + t32_b2;
+      tp.w3f = d_pack + t32_w3; tp.b3 = d_pack + t32_b3; tp.wc = d_pack + t32_wc;
+      tp.act1 = d.act; tp.act2 = ops[i + 1].d.act; tp.act3 = ops[i + 2].d.act; tp.act4 = ops[i + 3].d.act;
+      tp.aff_out = aff_out; tp.nan_guard = flags & SRCFD_FLAG_NAN_GUARD; tp.nonfinite = nonfinite; tp.out_dtype = out_dtype;
+      tp.seg = tail32_segments(n, d.MH, num_cus);
+      const std::string nm = op.name + "+" + ops[i + 1].name + "+" + ops[i + 2].name + "+" + ops[i + 3].name;
+      return launch(nm.c_str(), s, [&] { return launch_tail32(tp, num_cus, s); });
     }
     static const bool no_pair = [] { const char* e = getenv("SRCFD_NO_PAIR"); return e && atoi(e) != 0; }();
     static const bool no_triple = [] { const char* e = getenv("SRCFD_NO_TRIPLE"); return e && atoi(e) != 0; }();
@@ -489,6 +553,7 @@ static int finish_create(std::unique_ptr<Model>& m, srcfd_model** out) {
     build_plan(m->desc, m->ops, m->pack);
     plan_convt_pair(*m);
     plan_convt_triple(*m);
+    plan_tail32(*m);
   } catch (const std::exception& e) {
     set_error(e.what());
     return SRCFD_EINVAL;

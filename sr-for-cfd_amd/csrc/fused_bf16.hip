@@ -305,7 +305,7 @@ int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, cons
     int cur = 0;
     rc = m.launch("conv2d", s, [&] { return launch_enc_conv1_16(f16, xin, ain, fs->d_f32 + fs->c1w_off, fs->d_f32 + fs->c1b_off, fs->act[0], c, s); });
     if (rc) return rc;
-    const bool use_mid = [] { const char* e = getenv("SRCFD_MID"); return !e || atoi(e) != 0; }();  // 0: generic GEMMs (A/B, tests)
+    static const bool use_mid = [] { const char* e = getenv("SRCFD_MID"); return !e || atoi(e) != 0; }();  // 0: generic GEMMs (A/B, tests)
     int prev_layer = -1;
     for (const Op16& o : fs->ops) {
       if (use_mid && o.layer >= 5) break;  // ConvT#0 / ConvT#1 run in the fused mid kernel below
@@ -334,8 +334,15 @@ int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, cons
       mp.b0f = P.d_midb;
       mp.w1f = P.d_w1f;
       mp.b1f = P.d_midb + 128;
-      { const char* e = getenv("SRCFD_MID_ABLATE"); mp.ablate = e ? atoi(e) : 0; }
-      const int mid_waves = [] { const char* e = getenv("SRCFD_MID_WAVES"); return e ? atoi(e) : 8; }();
+      mp.ablate = 0;
+#ifdef SRCFD_DIAG
+      { static const int abl = [] { const char* e = getenv("SRCFD_MID_ABLATE"); return e ? atoi(e) : 0; }(); mp.ablate = abl; }
+#endif
+      static const int mid_waves = [] {  // read once; anything but 4 / 8 / 16 waves per workgroup is ignored
+        const char* e = getenv("SRCFD_MID_WAVES");
+        const int v = e ? atoi(e) : 8;
+        return (v == 4 || v == 8 || v == 16) ? v : 8;
+      }();
       rc = m.launch("mid(convT0+convT1)", s, [&] { return launch_mid16(f16, mp, mid_waves, s); });
       if (rc) return rc;
     }
@@ -351,18 +358,22 @@ int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, cons
     tp.nan_guard = flags & SRCFD_FLAG_NAN_GUARD;
     tp.nonfinite = nonfinite;
     tp.out_dtype = out_dtype;
-    { const char* e = getenv("SRCFD_TAIL_ABLATE"); tp.ablate = e ? atoi(e) : 0; }
-    static unsigned long long* d_prof = nullptr;   // SRCFD_TAIL_PROF=1: per-wave section timers of workgroup 0 (diagnostic)
+    tp.ablate = 0;
+    tp.prof = nullptr;
+#ifdef SRCFD_DIAG
+    { static const int abl = [] { const char* e = getenv("SRCFD_TAIL_ABLATE"); return e ? atoi(e) : 0; }(); tp.ablate = abl; }
+    static unsigned long long* d_prof = nullptr;   // SRCFD_TAIL_PROF=1: per-wave section timers of workgroup 0 (synchronises: never under graph capture)
     static int prof_calls = 0;
-    const bool prof = getenv("SRCFD_TAIL_PROF") != nullptr;
+    static const bool prof = getenv("SRCFD_TAIL_PROF") != nullptr;
     if (prof && !d_prof) HIPCHECK(hipMalloc(&d_prof, 16 * 5 * sizeof(unsigned long long)));
     tp.prof = prof ? d_prof : nullptr;
+#endif
     // Batches that do not fill the chip evenly (fewer samples than CUs, or a few more than a multiple of them): cut each
     // sample into S segments so that the longest workgroup walks fewer strips.  Cost of a choice = strips walked by the
     // busiest workgroup: ceil(n S / CUs) virtual samples of 50/S (+1 warm-up) strips, + 2 rounds of pipeline depth.
     int seg = 1;
-    { const char* e = getenv("SRCFD_TAIL_SEG");
-      if (e) seg = atoi(e);
+    { static const int seg_env = [] { const char* e = getenv("SRCFD_TAIL_SEG"); return e ? atoi(e) : 0; }();  // read once
+      if (seg_env) seg = seg_env;
       else {
         long best = ((long)(c + fs->num_cus - 1) / fs->num_cus) * 50 + 2;
         for (int cand : {2, 5, 10, 25}) {
@@ -375,6 +386,7 @@ int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, cons
     const int blocks = std::min(c * seg, fs->num_cus);
     rc = m.launch("tail(convT2-4+out)", s, [&] { return launch_tail16(f16, tp, blocks, s); });
     if (rc) return rc;
+#ifdef SRCFD_DIAG
     if (prof && ++prof_calls == 20) {
       unsigned long long h[80];
       HIPCHECK(hipStreamSynchronize(s));
@@ -383,6 +395,7 @@ int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, cons
       for (int w = 0; w < 16; ++w)
         fprintf(stderr, "  wave %2d: %9llu %9llu %9llu %9llu %9llu\n", w, h[w * 5], h[w * 5 + 1], h[w * 5 + 2], h[w * 5 + 3], h[w * 5 + 4]);
     }
+#endif
   }
   return SRCFD_OK;
 }

@@ -62,6 +62,30 @@ struct TripleDesc {
 };
 hipError_t launch_convt_triple_f32(const TripleDesc& d, const float* X, const float* w1, const float* b1, const float* w2, const float* b2,
                                    const float* w3, const float* b3, float* Y, hipStream_t s);
+// The last four layers of decoder_400 in f32 as ONE streaming kernel (kernels_tail32.hip): ConvT 64->32 -> ConvT 32->16 ->
+// ConvT 16->8 (all 2x2 stride 2) -> Conv 3x3 SAME 8->1 + de-standardise + NaN guard + output cast; the 8-channel
+// full-resolution activation lives in an LDS ring only.  Input (n, H, W, 64) f32 with W <= 50; output (n, 8H, 8W).
+struct Tail32Params {
+  const float* in;
+  void* out;
+  int n, H, W;
+  const float* w1f;   // [tap1 4][m-tile 2][k-step 16][64 lanes]: lane (m, kg) = W1[tap1][co 16t+m][ci 16kg+s]
+  const float* b1;    // [32]
+  const float* w2f;   // [tap2 4][k-step 8][64 lanes]: lane (m, kg), step 4t+i = W2[tap2][co m][ci 16t+4kg+i]
+  const float* b2;    // [16]
+  const float* w3f;   // [m-tile 2][k-step 4][64 lanes]: lane (m, kg) = W3[tap3 2u+(m>>3)][co m&7][ci 4kg+i]
+  const float* b3;    // [8]
+  const float* wc;    // [72] output conv (ty, tx, ci) + [1] bias
+  int act1, act2, act3, act4;
+  const float* aff_out;   // (n, 2) mean, std or null
+  int nan_guard;
+  unsigned long long* nonfinite;
+  int out_dtype;
+  int seg;            // segments per sample (a divisor of 2H)
+};
+hipError_t launch_tail32(const Tail32Params& p, int num_cus, hipStream_t s);
+int tail32_segments(int n, int H, int num_cus);
+
 // Last layer + de-standardise + NaN guard + output cast in one kernel, for the layers gemm_fuses_finalize() accepts.
 bool gemm_fuses_finalize(const GemmDesc& d);
 hipError_t launch_gemm_finalize(const GemmDesc& d, const float* X, const float* B, const float* bias, void* out, int out_dtype,

@@ -323,6 +323,14 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
+// Diagnostic work-skipping switches (TailParams::ablate) exist only in a -DSRCFD_DIAG build (make DIAG=1): the shipped
+// kernels carry no path that turns work off.
+#ifdef SRCFD_DIAG
+#define TAIL_ABL(bit) (p.ablate & (bit))
+#else
+#define TAIL_ABL(bit) 0
+#endif
+
 template <bool F16, int OUT, bool PROF = false, bool SEG = false>  // OUT: 0 f32, 1 bf16, 2 f16; PROF: per-wave section timers (diagnostic); SEG: samples cut into segments
 __global__ void __launch_bounds__(1024) tail16(TailParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -381,7 +389,7 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
     for (int kk = 0; kk < 4; ++kk) wa[kk] = w2_f[(a_mt * 4 + kk) * 64 + lane];
   }
 
-  const bool ab_sw = p.ablate & 1;
+  const bool ab_sw = TAIL_ABL(1);
   // This workgroup's samples k = 0..K-1 (ids blockIdx.x + k*gridDim.x) are treated as one tall image of
   // 400*K rows: strip g = 50*k + s.  Round r runs A(g=r), BC(g=r-1), D(g=r-2), so the pipeline never
   // drains between samples; D(g) covers rows 8g-1 .. 8g+6 of the tall image, and its first row pair at a
@@ -421,7 +429,7 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
     // ---------------- BC: ConvT#3 + ConvT#4 on 32 pixels of the 100-level ----------------
     auto do_bc = [&]() {
       const int g = r - 1;
-      if (!(bc_item >= 0 && g >= 0 && g < G && !(p.ablate & 8))) return;
+      if (!(bc_item >= 0 && g >= 0 && g < G && !TAIL_ABL(8))) return;
       { int sm, sx, sg, sl; strip_of(g, sm, sx, sg, sl); if (sx < 0) return; }  // warm-up strip of a top segment: nothing above the image
       const int t = bc_item >> 1, m3 = bc_item & 1;
       int idx = 32 * t + l31;
@@ -462,7 +470,7 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
     // One item = one output row pair (rp, wave-uniform) x 16 tiles of 2x8 pixels, so row slots and
     // validity live in SGPRs and each lane only adds its own column offset.
     const int gd = r - 2;
-    const bool d_on = gd >= 0 && !(p.ablate & 2);
+    const bool d_on = gd >= 0 && !TAIL_ABL(2);
     const int kd = gd >= 0 ? gd / SL : 0, sd = gd - SL * kd;   // virtual sample / local strip of D's strip
     int sample_d = 0, s_d = 0, seg_d = 0, sl_d = 0;            // real sample and actual strip (valid while gd < G)
     if (gd >= 0 && gd < G) strip_of(gd, sample_d, s_d, seg_d, sl_d);
@@ -555,9 +563,9 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
       // stagger: the BC-only-plus-D waves do their latency-bound D items first, so their VALU-heavy
       // BC items overlap the tail (A items) of the waves that started with BC
       if (PROF) ts[0] = __builtin_amdgcn_s_memtime();
-      const bool d_first_order = (p.ablate & 16) ? false : ((p.ablate & 32) ? true : wave >= 8);
+      const bool d_first_order = TAIL_ABL(16) ? false : (TAIL_ABL(32) ? true : wave >= 8);
       if (d_first_order) {
-        if (!(p.ablate & 128)) __builtin_amdgcn_s_setprio(3);  // D is a latency chain with few instructions: let it through
+        if (!TAIL_ABL(128)) __builtin_amdgcn_s_setprio(3);  // D is a latency chain with few instructions: let it through
         if (d_on && d_cnt >= 1) do_d(d_first);
         if (d_on && d_cnt >= 2) do_d(d_first + 1);
         __builtin_amdgcn_s_setprio(0);
@@ -566,7 +574,7 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
       do_bc();
       if (PROF) ts[2] = __builtin_amdgcn_s_memtime();
       if (!d_first_order) {
-        if (!(p.ablate & 128)) __builtin_amdgcn_s_setprio(3);
+        if (!TAIL_ABL(128)) __builtin_amdgcn_s_setprio(3);
         if (d_on && d_cnt >= 1) do_d(d_first);
         if (d_on && d_cnt >= 2) do_d(d_first + 1);
         __builtin_amdgcn_s_setprio(0);
@@ -577,7 +585,7 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
     // ---------------- A: ConvT#2 for strip g = r (input prefetched last round), then prefetch g+1 ----------------
     int a_smp = 0, a_s = -1, a_sg = 0, a_sl = 0;
     if (r < G) strip_of(r, a_smp, a_s, a_sg, a_sl);
-    if (hasA && r < G && !(p.ablate & 4)) {
+    if (hasA && r < G && !TAIL_ABL(4)) {
       int n_smp = 0, n_s = -1, n_sg = 0, n_sl = 0;
       if (r + 1 < G) strip_of(r + 1, n_smp, n_s, n_sg, n_sl);
       if (a_s < 0) {        // warm-up strip above the image: nothing to compute, only fetch the next strip's input

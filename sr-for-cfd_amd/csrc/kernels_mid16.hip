@@ -20,6 +20,12 @@
 
 namespace srcfd {
 
+#ifdef SRCFD_DIAG
+#define MID_ABL(bit) (p.ablate & (bit))
+#else
+#define MID_ABL(bit) 0   // diagnostic switches exist only in a -DSRCFD_DIAG build
+#endif
+
 constexpr int M_PITCH = 72;  // LDS row pitch in elements (144 B)
 
 // NW waves per workgroup, each owning 32 output pixels x 128 channels.  The weight tile (16 KB per
@@ -141,13 +147,13 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
     r2l_w();
     if (t == 0) r2l_p();
     __syncthreads();
-    if (s + 1 < NS && !(p.ablate & 4)) {
+    if (s + 1 < NS && !MID_ABL(4)) {
       const int c1 = (s + 1) / NT, t1 = (s + 1) - c1 * NT;
       g2r_w(t1, c1);
       if (t1 == 0) g2r_p(c1);
     }
     const uint16_t* bsrc = Ps + trow[t];
-    if (!(p.ablate & 1))
+    if (!MID_ABL(1))
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const uint4 bf = *reinterpret_cast<const uint4*>(bsrc + kk * 16);
@@ -180,7 +186,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
     for (int j = 0; j < W1CH; ++j)
       if (C::NTHR <= 512 || tid < 512) reinterpret_cast<u32x4*>(w1s)[buf * 512 + tid + C::NTHR * j] = w1r[j];
   };
-  if (!(p.ablate & 2)) {
+  if (!MID_ABL(2)) {
     r2l_w1(0);
     __syncthreads();
 #pragma unroll 1

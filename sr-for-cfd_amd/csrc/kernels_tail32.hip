@@ -1,0 +1,343 @@
+// tail32: the f32 (parity, <= 1e-5) path's last four layers as ONE streaming kernel (gfx950 only):
+//   ConvT 2x2 s2 64->32 -> ConvT 2x2 s2 32->16 -> ConvT 2x2 s2 16->8 -> Conv 3x3 SAME 8->1
+//   + de-standardise + NaN/Inf guard + output cast              (sr-ae-conv.ipynb:c283-286)
+//
+// Why: as separate launches the 8-channel 400x400 activation (5.12 MB per sample in f32) is written by one kernel and
+// re-read by the next -- 2 x 3.9 GB per 768 samples, 3.4 of the f32 path's 5.6 ms.  Here nothing between the 50x50x64
+// input and the final image touches HBM.
+//
+// Structure (the streaming-ring idea of tail16, re-done for f32 operands):
+//   * one 512-thread workgroup per CU walks its samples top to bottom in STRIPS of 4 output rows
+//     (= one first-layer tap row ty1 of one 50-level row); per round
+//       P: every wave takes one item = (16-pixel tile of the 50-level row, first-layer tap column tx1) and runs the
+//          three transposed convolutions in registers on v_mfma_f32_16x16x4_f32 (exact f32 products): rows = tap x
+//          channel, columns = the wave's 16 pixels, so the activated accumulators of one layer ARE the B operands of the
+//          next (lane (pixel n, group rg), register i holds channel 4 rg + i: k-step i of the next layer contracts
+//          channels {4 kg + i}, weights packed in that order on the host).  The 4x4x8 output block of every pixel goes
+//          to a 10-row LDS ring of the 400-level (f32, 32 B per pixel);
+//       D: the 3x3 output conv of the PREVIOUS strip's rows from the ring on the VALU (v_pk_fma_f32 runs at the f32
+//          MFMA rate, and the matrix pipe is busy with P), 4 adjacent pixels per lane, + de-standardise + guard,
+//          stored as whole 16-byte pieces of contiguous rows;
+//     waves 0-3 run P then D, waves 4-7 D then P, so that the two waves of a SIMD are in different phases
+//     (matrix work of one beside vector work of the other); one LDS-only barrier per round.
+//   * ring layout [row][channel half][x & 7 plane][x >> 3 slot] of 16-byte granules, 54 slots per plane (slot 0 and
+//     slots past the image stay zero = the SAME padding of the conv): P writes 16 consecutive slots per instruction, D
+//     reads consecutive x across lanes -> both conflict-free; one extra all-zero row stands in for rows outside the image.
+//   * small batches: a sample is cut into S segments of consecutive strips ("virtual samples"), each preceded by one
+//     warm-up strip that refills the two ring rows its first output row reads; every output pixel goes through the same
+//     arithmetic whatever S is (results are bit-identical across batch sizes).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "act_device.h"
+#include "kernels.h"
+#include "kernels16.h"  // lds_attr_once
+
+namespace srcfd {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int R_SLOTS = 54;                       // granules per plane: 1 + 50 + padding (plane stride 864 B = 96 mod 256)
+constexpr int R_PLANE = R_SLOTS * 16;             // 864
+constexpr int R_HALF = 8 * R_PLANE;               // 6912: channels 0-3 | 4-7
+constexpr int R_ROW = 2 * R_HALF;                 // 13824
+constexpr int R_ROWS = 10;
+constexpr int R_ZROW = R_ROWS * R_ROW;            // byte offset of the all-zero row
+constexpr int R_WC = (R_ROWS + 1) * R_ROW;        // output-conv weights [9 taps][8] f32 + bias (wave-uniform broadcast reads)
+constexpr int R_W2 = R_WC + 320;                  // second / third layer A operands (8 KB + 2 KB): one conflict-free ds_read_b32 per MFMA
+constexpr int R_W3 = R_W2 + 4 * 8 * 64 * 4;       // (held in registers they cost 40 of the 256 a wave has: the kernel spilled)
+constexpr int T32_LDS = R_W3 + 2 * 4 * 64 * 4;    // 162624
+static_assert(T32_LDS <= 160 * 1024, "tail32 LDS budget");
+
+__device__ __forceinline__ void lds_barrier32() {  // LDS traffic complete, global loads / stores stay in flight
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// The layers this kernel fuses are swish or linear (the host falls back to the layer-by-layer launches otherwise).
+__device__ __forceinline__ float act32(float v, int act) { return act == SRCFD_ACT_SWISH ? v * sigmoid_fast(v) : v; }
+__device__ __forceinline__ f32x4 act32x4(f32x4 v, int act) {
+  if (act != SRCFD_ACT_SWISH) return v;
+  f32x4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = v[i] * sigmoid_fast(v[i]);
+  return r;
+}
+
+// One strip of one (virtual) sample as the pipeline sees it.
+struct Strip {
+  int valid;   // 0: nothing (before the first / after the last job)
+  int smp;     // real sample
+  int g;       // strip index in the sample, 0 .. 2H-1 (row y = g >> 1, first-layer tap row ty1 = g & 1)
+  int warm;    // warm-up strip of a segment: computed for the ring only, its rows belong to the previous segment
+};
+
+template <int OUT>  // 0 f32, 1 bf16, 2 f16
+__global__ void __launch_bounds__(512) tail32(Tail32Params p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, rg = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int H = p.H, W = p.W, SH = 2 * H, OW = 8 * W, OHs = 8 * H;
+
+  for (int i = tid; i < R_WC / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+  if (tid < 80) reinterpret_cast<float*>(smem + R_WC)[tid] = tid < 73 ? p.wc[tid] : 0.f;
+  for (int i = tid; i < 4 * 8 * 64; i += 512) reinterpret_cast<float*>(smem + R_W2)[i] = p.w2f[i];
+  reinterpret_cast<float*>(smem + R_W3)[tid] = p.w3f[tid];   // 2 * 4 * 64 = 512 floats
+
+  // ---- P role: item = (tile, tx1) ----
+  const int tile = wave & 3, tx1 = wave >> 2;
+  const int px = 16 * tile + n;
+  const bool px_ok = px < W;
+  const int pxc = px_ok ? px : W - 1;
+  const bool tile_on = 16 * tile < W;   // wave-uniform: tiles wholly past the row do nothing
+  float wA[2][2][16];
+  const float* wB = reinterpret_cast<const float*>(smem + R_W2) + lane;   // [(2 ty2 + tx2) * 8 + ks][64]
+  const float* wC = reinterpret_cast<const float*>(smem + R_W3) + lane;   // [u * 4 + i][64]
+  f32x4 bA[2], bB, bC;
+#pragma unroll
+  for (int ty1 = 0; ty1 < 2; ++ty1)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int s = 0; s < 16; ++s) wA[ty1][t][s] = p.w1f[((((2 * ty1 + tx1) * 2 + t) * 16) + s) * 64 + lane];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bA[t][i] = p.b1[16 * t + 4 * rg + i];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { bB[i] = p.b2[4 * rg + i]; bC[i] = p.b3[4 * (rg & 1) + i]; }
+  // ring byte offset of this lane's granule, without the row and the 2*tx2 plane term
+  const int p_off = (rg & 1) * R_HALF + (4 * tx1 + (rg >> 1)) * R_PLANE + (px + 1) * 16;
+
+  // ---- D role: row q of the strip, 4 adjacent pixels per lane ----
+  const int dq = wave >> 1;
+  const int db = (wave & 1) * W + lane;           // x-block, 0 .. 2W-1
+  const bool d_lane = lane < W;
+  const int dbc = d_lane ? db : 0;
+  const int d_c = (4 * (dbc & 1)) * R_PLANE + ((dbc >> 1) + 1) * 16;                                   // columns X0 .. X0+3: + j * R_PLANE
+  const int d_l = (dbc & 1) ? 3 * R_PLANE + ((dbc >> 1) + 1) * 16 : 7 * R_PLANE + (dbc >> 1) * 16;      // column X0 - 1
+  const int d_r = (dbc & 1) ? ((dbc >> 1) + 2) * 16 : 4 * R_PLANE + ((dbc >> 1) + 1) * 16;              // column X0 + 4
+  const f32x4* wk = reinterpret_cast<const f32x4*>(smem + R_WC);   // [tap][half]
+  unsigned bad_total = 0;
+
+  // ---- job iterator: virtual samples blockIdx.x + j * gridDim.x, each a run of strips.  Plain scalars kept wave-uniform
+  // (readfirstlane) so that the whole bookkeeping runs on the scalar unit.
+#define UNI(x) __builtin_amdgcn_readfirstlane(x)
+  const int S = p.seg > 1 ? p.seg : 1, L = SH / S, NV = p.n * S;
+  int it_jv = (int)blockIdx.x, it_g1 = 0;
+  Strip it{0, 0, 0, 0};
+  // first strip of virtual sample it_jv (warm-up strip first, unless the segment starts at the top of the image)
+#define JOB_START()                                                                     \
+  do {                                                                                  \
+    if (it_jv < NV) {                                                                   \
+      const int smp_ = it_jv / S, seg_ = it_jv - smp_ * S, g0_ = seg_ * L;              \
+      it.valid = 1; it.smp = UNI(smp_); it.g = UNI(g0_ > 0 ? g0_ - 1 : 0); it.warm = UNI(g0_ > 0 ? 1 : 0); \
+      it_g1 = UNI(g0_ + L);                                                             \
+    } else it.valid = 0;                                                                \
+  } while (0)
+  JOB_START();
+  Strip cur = it, d1{0, 0, 0, 0}, d2{0, 0, 0, 0};
+
+  auto load_x = [&](const Strip& s, f32x4 (&x)[4]) {
+    const float* src = p.in + ((((size_t)s.smp * H + (s.g >> 1)) * W + pxc) * 64 + 16 * rg);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) x[q] = *reinterpret_cast<const f32x4*>(src + 4 * q);
+  };
+  f32x4 xs[4], xn[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { xs[q] = f32x4{0, 0, 0, 0}; xn[q] = f32x4{0, 0, 0, 0}; }
+  if (cur.valid && tile_on) load_x(cur, xs);
+  __syncthreads();
+
+  int ring0 = 0;  // ring row of this round's strip row 0: (4 * round) % 10
+  for (;;) {
+    if (!cur.valid && !d1.valid && !d2.valid) break;
+    // the strip after this one: fetch its input now when it is a different 50-level row
+    if (it.valid) {                      // one strip further
+      if (it.g + 1 < it_g1) { it.g = it.g + 1; it.warm = 0; }
+      else { it_jv = UNI(it_jv + (int)gridDim.x); JOB_START(); }
+    }
+    const Strip nxt = it;
+    const bool fetch = nxt.valid && tile_on && (!cur.valid || nxt.smp != cur.smp || (nxt.g >> 1) != (cur.g >> 1));
+    if (fetch) load_x(nxt, xn);
+
+    // ---------------- P ----------------
+    auto first_layer = [&](auto TY1, f32x4& a0, f32x4& a1) {
+      constexpr int ty1 = decltype(TY1)::value;
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const float xv = xs[s >> 2][s & 3];
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[ty1][0][s], xv, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[ty1][1][s], xv, a1, 0, 0, 0);
+      }
+    };
+    auto run_p = [&]() {
+      if (!(cur.valid && tile_on)) return;
+      f32x4 a0 = bA[0], a1 = bA[1];
+      if (cur.g & 1) first_layer(std::integral_constant<int, 1>{}, a0, a1);
+      else first_layer(std::integral_constant<int, 0>{}, a0, a1);
+      a0 = act32x4(a0, p.act1); a1 = act32x4(a1, p.act1);
+#pragma unroll
+      for (int ty2 = 0; ty2 < 2; ++ty2) {
+        f32x4 b0 = bB, b1 = bB;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          const float bv = ks < 4 ? a0[ks & 3] : a1[ks & 3];
+          b0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wB[((2 * ty2) * 8 + ks) * 64], bv, b0, 0, 0, 0);
+          b1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wB[((2 * ty2 + 1) * 8 + ks) * 64], bv, b1, 0, 0, 0);
+        }
+        b0 = act32x4(b0, p.act2); b1 = act32x4(b1, p.act2);
+#pragma unroll
+        for (int tx2 = 0; tx2 < 2; ++tx2) {
+          const f32x4 bs = tx2 ? b1 : b0;
+          f32x4 c0 = bC, c1 = bC;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wC[i * 64], bs[i], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wC[(4 + i) * 64], bs[i], c1, 0, 0, 0);
+          }
+          c0 = act32x4(c0, p.act3); c1 = act32x4(c1, p.act3);
+          if (px_ok) {
+            int r0 = ring0 + 2 * ty2, r1 = r0 + 1;
+            r0 = r0 >= R_ROWS ? r0 - R_ROWS : r0;
+            r1 = r1 >= R_ROWS ? r1 - R_ROWS : r1;
+            *reinterpret_cast<f32x4*>(smem + r0 * R_ROW + p_off + 2 * tx2 * R_PLANE) = c0;
+            *reinterpret_cast<f32x4*>(smem + r1 * R_ROW + p_off + 2 * tx2 * R_PLANE) = c1;
+          }
+        }
+      }
+    };
+
+    // ---------------- D ----------------
+    // Row q of this wave.  q == 0: row 3 of the strip issued two rounds ago (its lower neighbour is row 0 of last round's
+    // strip, or the zero row at the bottom of the image); q = 1..3: row q-1 of last round's strip.
+    auto run_d = [&]() {
+      int smp, yl;                       // output row (sample, local row)
+      int ro0, ro1, ro2;                 // ring byte offsets of the three window rows
+      const int base = ring0 + 2 * R_ROWS - 4;   // ring row of last round's strip row 0, + R_ROWS so that differences stay positive
+      bool on;
+      if (dq == 0) {
+        const bool below = d1.valid && d1.smp == d2.smp && d1.g == d2.g + 1;
+        on = d2.valid && (below || d2.g == SH - 1);
+        smp = d2.smp; yl = 4 * d2.g + 3;
+        ro0 = ((base - 2) % R_ROWS) * R_ROW;
+        ro1 = ((base - 1) % R_ROWS) * R_ROW;
+        ro2 = below ? (base % R_ROWS) * R_ROW : R_ZROW;
+      } else {
+        on = d1.valid && !d1.warm;
+        smp = d1.smp; yl = 4 * d1.g + dq - 1;
+        const bool above = dq > 1 || (d2.valid && d2.smp == d1.smp && d2.g + 1 == d1.g);   // else: top of the image
+        ro0 = above ? ((base + dq - 2) % R_ROWS) * R_ROW : R_ZROW;
+        ro1 = ((base + dq - 1) % R_ROWS) * R_ROW;
+        ro2 = ((base + dq) % R_ROWS) * R_ROW;
+      }
+      if (!on || !d_lane) return;
+      const float cbias = reinterpret_cast<const float*>(smem + R_WC)[72];
+      f32x2 acc[4];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) acc[o] = f32x2{cbias, 0.f};
+      auto window_row = [&](auto DY, const int ro) {
+        constexpr int dy = decltype(DY)::value;
+        const char* rowp = smem + ro;
+        f32x4 lo[6], hi[6];                 // window columns X0 - 1 .. X0 + 4 of this row
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+          const char* gp = rowp + (j == 0 ? d_l : (j == 5 ? d_r : d_c + (j - 1) * R_PLANE));
+          lo[j] = *reinterpret_cast<const f32x4*>(gp);
+          hi[j] = *reinterpret_cast<const f32x4*>(gp + R_HALF);
+        }
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+          const f32x4 wl = wk[(dy * 3 + dx) * 2], wh = wk[(dy * 3 + dx) * 2 + 1];
+#pragma unroll
+          for (int o = 0; o < 4; ++o) {
+            const int j = o + dx;           // column X0 + o + (dx - 1)
+            acc[o] = __builtin_elementwise_fma(f32x2{lo[j][0], lo[j][1]}, f32x2{wl[0], wl[1]}, acc[o]);
+            acc[o] = __builtin_elementwise_fma(f32x2{lo[j][2], lo[j][3]}, f32x2{wl[2], wl[3]}, acc[o]);
+            acc[o] = __builtin_elementwise_fma(f32x2{hi[j][0], hi[j][1]}, f32x2{wh[0], wh[1]}, acc[o]);
+            acc[o] = __builtin_elementwise_fma(f32x2{hi[j][2], hi[j][3]}, f32x2{wh[2], wh[3]}, acc[o]);
+          }
+        }
+        // one window row (48 + 24 registers) in flight at a time: left alone the compiler issues all 54 LDS reads of the
+        // three rows first (216 registers) and spills the resident first-layer weights
+        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : : "memory");
+      };
+      window_row(std::integral_constant<int, 0>{}, ro0);
+      window_row(std::integral_constant<int, 1>{}, ro1);
+      window_row(std::integral_constant<int, 2>{}, ro2);
+      float mean = 0.f, sd = 1.f;
+      if (p.aff_out) { mean = p.aff_out[2 * smp]; sd = p.aff_out[2 * smp + 1]; }
+      float v[4];
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        float t = act32(acc[o][0] + acc[o][1], p.act4);
+        if (p.aff_out) t = __fadd_rn(__fmul_rn(t, sd), mean);
+        if (p.nan_guard) {
+          const bool bad = !(fabsf(t) <= 3.402823466e38f);
+          bad_total += (unsigned)__popcll(__ballot(bad));
+          t = bad ? 0.f : t;
+        }
+        v[o] = t;
+      }
+      const size_t o0 = ((size_t)smp * OHs + yl) * OW + 4 * db;
+      if (OUT == 0) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o0) = f32x4{v[0], v[1], v[2], v[3]};
+      else {
+        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+        typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+        const f32x4 vv = {v[0], v[1], v[2], v[3]};
+        uint2 pk;
+        if (OUT == 1) pk = __builtin_bit_cast(uint2, __builtin_convertvector(vv, bf16x4));
+        else pk = __builtin_bit_cast(uint2, __builtin_convertvector(vv, h16x4));
+        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + o0) = pk;
+      }
+    };
+
+    // one copy of each phase in the code; waves 4-7 take them in the other order
+#pragma nounroll
+    for (int ph = 0; ph < 2; ++ph) {
+      if ((ph == 0) == (wave < 4)) run_p();
+      else run_d();
+    }
+
+    lds_barrier32();
+    if (fetch) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) xs[q] = xn[q];
+    }
+    d2 = d1; d1 = cur; cur = nxt;
+    ring0 += 4;
+    ring0 = ring0 >= R_ROWS ? ring0 - R_ROWS : ring0;
+  }
+  if (p.nan_guard && p.nonfinite && bad_total && lane == 0) atomicAdd(p.nonfinite, (unsigned long long)bad_total);
+}
+
+hipError_t launch_tail32(const Tail32Params& p, int num_cus, hipStream_t s) {
+  if (p.n == 0) return hipSuccess;
+  void (*fn)(Tail32Params) = p.out_dtype == SRCFD_F32 ? tail32<0> : (p.out_dtype == SRCFD_BF16 ? tail32<1> : tail32<2>);
+  hipError_t e = lds_attr_once(reinterpret_cast<const void*>(fn), T32_LDS);
+  if (e != hipSuccess) return e;
+  const int S = p.seg > 1 ? p.seg : 1;
+  const int blocks = (int)std::min<int64_t>((int64_t)p.n * S, num_cus);
+  hipLaunchKernelGGL(fn, dim3(blocks), dim3(512), T32_LDS, s, p);
+  return hipGetLastError();
+}
+
+// Segments per sample for a batch of n samples of 2H strips each: the busiest workgroup walks ceil(n S / CUs) virtual
+// samples of 2H/S (+1 warm-up) strips, + 2 rounds of pipeline depth; more segments must buy 10 % to be taken.
+int tail32_segments(int n, int H, int num_cus) {
+  const int SH = 2 * H;
+  long best = ((long)(n + num_cus - 1) / num_cus) * SH + 2;
+  int seg = 1;
+  for (int cand = 2; cand <= SH; ++cand) {
+    if (SH % cand) continue;
+    const long cost = ((long)((long)n * cand + num_cus - 1) / num_cus) * (SH / cand + 1) + 2;
+    if (cost * 110 < best * 100) { best = cost; seg = cand; }
+  }
+  return seg;
+}
+
+}  // namespace srcfd

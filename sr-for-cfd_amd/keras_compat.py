@@ -29,7 +29,40 @@ import numpy as np
 from .engine import SRModel, device_count
 
 _DEFAULT_PRECISION = os.environ.get("SRCFD_PRECISION", "fp32")
-_HANDLE_CACHE: Dict[Tuple, SRModel] = {}
+# (paths, precision, device) -> (mtimes of the files when loaded, handle).  One entry per file pair: a re-saved file
+# (new mtime) closes and replaces the stale handle instead of piling up device memory next to it.
+_HANDLE_CACHE: Dict[Tuple, Tuple[Tuple, SRModel]] = {}
+_DEFAULT_DEVICE: Optional[int] = None
+
+
+def set_default_device(index: Optional[int]) -> None:
+    """GPU the Keras-style surface runs on.  None (default): torch's current CUDA device when torch is already imported
+    and initialised, else LOCAL_RANK (one process per GPU under torch.distributed.run), else device 0."""
+    global _DEFAULT_DEVICE
+    _DEFAULT_DEVICE = None if index is None else int(index)
+
+
+def _pick_device() -> int:
+    n = device_count()
+    if n <= 0:
+        return -1
+    if _DEFAULT_DEVICE is not None:
+        return _DEFAULT_DEVICE
+    import sys
+    torch = sys.modules.get("torch")
+    if torch is not None and torch.cuda.is_available() and torch.cuda.is_initialized():
+        return int(torch.cuda.current_device())
+    try:
+        return int(os.environ.get("LOCAL_RANK", "0")) % n
+    except ValueError:
+        return 0
+
+
+def clear_handle_cache() -> None:
+    """Closes every cached device handle (weights + workspace)."""
+    for _, m in _HANDLE_CACHE.values():
+        m.close()
+    _HANDLE_CACHE.clear()
 
 
 def set_default_precision(name: str) -> None:
@@ -56,16 +89,22 @@ class _Symbolic:
     __add__ = __radd__ = __sub__ = __rsub__ = __mul__ = __rmul__ = __truediv__ = __getitem__ = _no
 
 
-def _device_handle(paths: Tuple[Optional[str], ...], precision: str) -> SRModel:
-    key = tuple((p, os.path.getmtime(p)) if p else None for p in paths) + (precision,)
-    m = _HANDLE_CACHE.get(key)
-    if m is None:
-        enc, dec = (paths + (None,))[:2]
-        m = SRModel.load_h5(enc, dec, device=0 if device_count() > 0 else -1)
-        if precision in ("bf16", "f16") and not m.has_fused_path:
-            precision = "fp32"  # the fused path needs the encoder_10 + decoder_400 pair
-        m.precision = precision
-        _HANDLE_CACHE[key] = m
+def _device_handle(paths: Tuple[Optional[str], ...], precision: str, device: Optional[int] = None) -> SRModel:
+    dev = _pick_device() if device is None else int(device)
+    key = (paths, precision, dev)
+    stamp = tuple(os.path.getmtime(p) if p else None for p in paths)
+    hit = _HANDLE_CACHE.get(key)
+    if hit is not None and hit[0] == stamp:
+        return hit[1]
+    if hit is not None:       # the file was re-saved: drop the stale handle and its device memory
+        hit[1].close()
+        del _HANDLE_CACHE[key]
+    enc, dec = (paths + (None,))[:2]
+    m = SRModel.load_h5(enc, dec, device=dev)
+    if precision in ("bf16", "f16") and not m.has_fused_path:
+        precision = "fp32"  # the fused path needs the encoder_10 + decoder_400 pair
+    m.precision = precision
+    _HANDLE_CACHE[key] = (stamp, m)
     return m
 
 

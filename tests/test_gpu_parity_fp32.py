@@ -341,10 +341,61 @@ def test_chained_transposed_convolutions(srcfd, oracle, chain, monkeypatch):
     m.predict(x)
     names = [nm for nm, _ in m.get_profile()]
     m.set_profiling(False)
-    assert sum("+" in nm for nm in names) == 1 and max(nm.count("+") for nm in names) == len(chain) - 2, names
+    # the 64 -> 32 -> 16 -> 8 chain followed by the 3x3 output conv is the streaming tail32 kernel (4 layers, one launch)
+    assert sum("+" in nm for nm in names) == 1 and max(nm.count("+") for nm in names) == (3 if len(chain) == 4 else 1), names
     m.precision = "fp32_naive"
     assert oracle.rel_l2(m.predict(x), ref) <= TOL_FP32
     # a batch that is not the first in its buffer: rows of a bigger batch equal the small batch's (per-pixel independence)
     m.precision = "fp32"
     big = np.concatenate([x, rng.standard_normal((5, h, w, chain[0])).astype(np.float32)])
     np.testing.assert_array_equal(m.predict(big)[:n], y)
+
+
+@pytest.mark.parametrize("h,w", [(6, 50), (3, 33), (1, 16), (4, 17), (9, 1)])
+def test_streaming_f32_tail_shapes_and_segmentation(srcfd, oracle, h, w):
+    """tail32 (ConvT 64->32->16->8 + 3x3 conv 8->1 + de-standardise + guard, one streaming kernel): image widths that leave
+    the last 16-pixel tile partial or empty, heights of one row, batch sizes that make the launcher cut samples into
+    1 .. 2H segments (warm-up strips, seams between samples and segments), against the float64 oracle; and every batch
+    size must give the same bits for the same sample."""
+    require_gpu(srcfd)
+    rng = np.random.default_rng(100 * h + w)
+    chain = (64, 32, 16, 8)
+    specs = []
+    ref_layers = []
+    for i in range(3):
+        cin, cout = chain[i], chain[i + 1]
+        wt = rng.standard_normal((2, 2, cout, cin)).astype(np.float32) / np.sqrt(cin)
+        b = rng.standard_normal(cout).astype(np.float32) * 0.1
+        ref_layers.append((wt, b))
+        specs.append(dict(kind="conv2d_transpose", k=2, stride=2, same=False, act="swish", w=wt, b=b))
+    wo = rng.standard_normal((3, 3, 8, 1)).astype(np.float32) / np.sqrt(72)
+    bo = rng.standard_normal(1).astype(np.float32) * 0.1
+    specs.append(dict(kind="conv2d", k=3, stride=1, same=True, act="linear", w=wo, b=bo))
+    m = srcfd.SRModel.from_layers(specs, (h, w, 64), device=0)
+    n_big = 300 if h * w <= 64 else 37
+    x = rng.standard_normal((n_big, h, w, 64)).astype(np.float32)
+    aout = np.stack([rng.standard_normal(n_big) * 0.3, rng.uniform(0.5, 2.0, n_big)], 1).astype(np.float32)
+    k = 3
+    ref = x[:k].astype(np.float64)
+    for wt, b in ref_layers:
+        ref = oracle.conv2d_transpose(ref, wt, b, 2, "valid", "swish")
+    ref = oracle.conv2d(ref, wo, bo, 1, "same", "linear")
+    ref = ref * aout[:k, 1].reshape(-1, 1, 1, 1).astype(np.float64) + aout[:k, 0].reshape(-1, 1, 1, 1).astype(np.float64)
+    y_big = m.predict(x, out_affine=aout)
+    assert y_big.shape == (n_big, 8 * h, 8 * w, 1)
+    assert oracle.rel_l2(y_big[:k], ref) <= TOL_FP32
+    m.set_profiling(True)
+    m.predict(x[:1], out_affine=aout[:1])
+    names = [nm for nm, _ in m.get_profile()]
+    m.set_profiling(False)
+    assert len(names) == 2 and names[1].count("+") == 3, names          # standardize + the fused tail
+    for n in (1, 2, 5, n_big - 1):                                      # different segment counts, same bits per sample
+        np.testing.assert_array_equal(m.predict(x[:n], out_affine=aout[:n]), y_big[:n])
+    # NaN guard inside the fused epilogue: poison one input pixel of sample 1
+    xb = x[:4].copy()
+    xb[1, h // 2, w // 2, 5] = np.nan
+    yb, bad = m.predict(xb, out_affine=aout[:4], nan_guard=True, return_nonfinite=True)
+    assert bad > 0 and np.isfinite(yb).all()
+    np.testing.assert_array_equal(yb[0], y_big[0])
+    np.testing.assert_array_equal(yb[2:], y_big[2:4])
+    assert int((yb[1] == 0).sum()) >= bad
