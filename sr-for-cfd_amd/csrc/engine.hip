@@ -213,8 +213,8 @@ static void plan_tail32(Model& m) {
   const Layer& LO = m.desc.layers[last.layer];
   if (LO.kind != SRCFD_LAYER_CONV2D || LO.kh != 3 || LO.kw != 3 || LO.stride != 1 || !LO.same || LO.cin != 8 || LO.cout != 1) return;
   if (m.ops[i].d.MW > 50) return;  // the LDS ring holds rows of up to 400 pixels
-  for (const Layer* L : {&L1, &L2, &L3, &LO})
-    if (L->act != SRCFD_ACT_SWISH && L->act != SRCFD_ACT_LINEAR) return;
+  if (L1.act != SRCFD_ACT_SWISH || L2.act != SRCFD_ACT_SWISH || L3.act != SRCFD_ACT_SWISH || LO.act != SRCFD_ACT_LINEAR) return;
+  const double LOG2E = 1.4426950408889634;   // swish layers produce log2(e) x (kernels_tail32.hip, swish_l2e)
   auto& pk = m.pack;
   auto align = [&]() { while (pk.size() % 64) pk.push_back(0.f); };
   align(); m.t32_w1 = pk.size(); pk.resize(pk.size() + 4 * 2 * 16 * 64);
@@ -223,9 +223,9 @@ static void plan_tail32(Model& m) {
       for (int s = 0; s < 16; ++s)
         for (int lane = 0; lane < 64; ++lane) {
           const int mm = lane & 15, kg = lane >> 4;
-          pk[m.t32_w1 + (size_t)((tap * 2 + t) * 16 + s) * 64 + lane] = L1.kernel[((size_t)tap * 32 + 16 * t + mm) * 64 + 16 * kg + s];
+          pk[m.t32_w1 + (size_t)((tap * 2 + t) * 16 + s) * 64 + lane] = (float)(L1.kernel[((size_t)tap * 32 + 16 * t + mm) * 64 + 16 * kg + s] * LOG2E);
         }
-  align(); m.t32_b1 = pk.size(); pk.insert(pk.end(), L1.bias.begin(), L1.bias.end());
+  align(); m.t32_b1 = pk.size(); for (float v : L1.bias) pk.push_back((float)(v * LOG2E));
   align(); m.t32_w2 = pk.size(); pk.resize(pk.size() + 4 * 8 * 64);
   for (int tap = 0; tap < 4; ++tap)
     for (int t = 0; t < 2; ++t)
@@ -234,7 +234,7 @@ static void plan_tail32(Model& m) {
           const int mm = lane & 15, kg = lane >> 4;
           pk[m.t32_w2 + (size_t)(tap * 8 + 4 * t + ii) * 64 + lane] = L2.kernel[((size_t)tap * 16 + mm) * 32 + 16 * t + 4 * kg + ii];
         }
-  align(); m.t32_b2 = pk.size(); pk.insert(pk.end(), L2.bias.begin(), L2.bias.end());
+  align(); m.t32_b2 = pk.size(); for (float v : L2.bias) pk.push_back((float)(v * LOG2E));
   align(); m.t32_w3 = pk.size(); pk.resize(pk.size() + 2 * 4 * 64);
   for (int u = 0; u < 2; ++u)
     for (int ii = 0; ii < 4; ++ii)
@@ -242,8 +242,8 @@ static void plan_tail32(Model& m) {
         const int mm = lane & 15, kg = lane >> 4;
         pk[m.t32_w3 + (size_t)(u * 4 + ii) * 64 + lane] = L3.kernel[((size_t)(2 * u + (mm >> 3)) * 8 + (mm & 7)) * 16 + 4 * kg + ii];
       }
-  align(); m.t32_b3 = pk.size(); pk.insert(pk.end(), L3.bias.begin(), L3.bias.end());
-  align(); m.t32_wc = pk.size(); pk.insert(pk.end(), LO.kernel.begin(), LO.kernel.end()); pk.push_back(LO.bias[0]);
+  align(); m.t32_b3 = pk.size(); for (float v : L3.bias) pk.push_back((float)(v * LOG2E));
+  align(); m.t32_wc = pk.size(); for (float v : LO.kernel) pk.push_back((float)(v / LOG2E)); pk.push_back(LO.bias[0]);
   align();
   m.tail32_op = (int)i;
 }
@@ -379,7 +379,6 @@ int Model::forward_generic(const float* x_dev, int n, const float* aff_in, const
       tp.in = X; tp.out = y_dev; tp.n = n; tp.H = d.MH; tp.W = d.MW;
       tp.w1f = d_pack + t32_w1; tp.b1 = d_pack + t32_b1; tp.w2f = d_pack + t32_w2; tp.b2 = d_pack + t32_b2;
       tp.w3f = d_pack + t32_w3; tp.b3 = d_pack + t32_b3; tp.wc = d_pack + t32_wc;
-      tp.act1 = d.act; tp.act2 = ops[i + 1].d.act; tp.act3 = ops[i + 2].d.act; tp.act4 = ops[i + 3].d.act;
       tp.aff_out = aff_out; tp.nan_guard = flags & SRCFD_FLAG_NAN_GUARD; tp.nonfinite = nonfinite; tp.out_dtype = out_dtype;
       tp.seg = tail32_segments(n, d.MH, num_cus);
       const std::string nm = op.name + "+" + ops[i + 1].name + "+" + ops[i + 2].name + "+" + ops[i + 3].name;

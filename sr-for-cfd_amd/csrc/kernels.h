@@ -65,6 +65,8 @@ hipError_t launch_convt_triple_f32(const TripleDesc& d, const float* X, const fl
 // The last four layers of decoder_400 in f32 as ONE streaming kernel (kernels_tail32.hip): ConvT 64->32 -> ConvT 32->16 ->
 // ConvT 16->8 (all 2x2 stride 2) -> Conv 3x3 SAME 8->1 + de-standardise + NaN guard + output cast; the 8-channel
 // full-resolution activation lives in an LDS ring only.  Input (n, H, W, 64) f32 with W <= 50; output (n, 8H, 8W).
+// The three transposed convolutions are swish, the output conv linear; w1f, b1, b2, b3 carry a factor log2(e), wc 1/log2(e)
+// (kernels_tail32.hip, swish_l2e).
 struct Tail32Params {
   const float* in;
   void* out;
@@ -76,7 +78,6 @@ struct Tail32Params {
   const float* w3f;   // [m-tile 2][k-step 4][64 lanes]: lane (m, kg) = W3[tap3 2u+(m>>3)][co m&7][ci 4kg+i]
   const float* b3;    // [8]
   const float* wc;    // [72] output conv (ty, tx, ci) + [1] bias
-  int act1, act2, act3, act4;
   const float* aff_out;   // (n, 2) mean, std or null
   int nan_guard;
   unsigned long long* nonfinite;

@@ -49,7 +49,8 @@ constexpr int R_ZROW = R_ROWS * R_ROW;            // byte offset of the all-zero
 constexpr int R_WC = (R_ROWS + 1) * R_ROW;        // output-conv weights [9 taps][8] f32 + bias (wave-uniform broadcast reads)
 constexpr int R_W2 = R_WC + 320;                  // second / third layer A operands (8 KB + 2 KB): one conflict-free ds_read_b32 per MFMA
 constexpr int R_W3 = R_W2 + 4 * 8 * 64 * 4;       // (held in registers they cost 40 of the 256 a wave has: the kernel spilled)
-constexpr int T32_LDS = R_W3 + 2 * 4 * 64 * 4;    // 162624
+constexpr int R_DUMP = R_W3 + 2 * 4 * 64 * 4;     // 64 granules: where lanes / rounds with nothing to store write (keeps the body branch-free)
+constexpr int T32_LDS = R_DUMP + 64 * 16;         // 163648
 static_assert(T32_LDS <= 160 * 1024, "tail32 LDS budget");
 
 __device__ __forceinline__ void lds_barrier32() {  // LDS traffic complete, global loads / stores stay in flight
@@ -58,14 +59,23 @@ __device__ __forceinline__ void lds_barrier32() {  // LDS traffic complete, glob
   asm volatile("" ::: "memory");
 }
 
-// The layers this kernel fuses are swish or linear (the host falls back to the layer-by-layer launches otherwise).
-__device__ __forceinline__ float act32(float v, int act) { return act == SRCFD_ACT_SWISH ? v * sigmoid_fast(v) : v; }
-__device__ __forceinline__ f32x4 act32x4(f32x4 v, int act) {
-  if (act != SRCFD_ACT_SWISH) return v;
-  f32x4 r;
+// The three transposed convolutions are swish, the output conv linear (decoder_400; the host falls back to the
+// layer-by-layer launches for anything else).  Every swish layer produces u = log2(e) x (first-layer weights and all biases
+// scaled on the host) and the epilogue computes u * rcp(1 + exp2(-u)) = log2(e) swish(x): one v_exp_f32 with a negated
+// source, one add, one v_rcp_f32, one multiply.  Between swish layers the factors cancel (weights unscaled); the output
+// conv's weights absorb the last 1/log2(e).  exp2 and rcp are good to ~1 ulp each, an order of magnitude inside the 1e-5
+// bar; for u -> -inf: exp2 = inf, rcp = 0, u * 0 = -0 (no NaN); a NaN stays a NaN.
+// On this chip f32 MFMAs and vector instructions of the waves of a SIMD do NOT overlap (tools/microbench8.hip: their times
+// add), so every vector instruction dropped here is kernel time: the Newton-refined sigmoid of the layer-by-layer path
+// costs 7 instructions per activation, this 4 (3 with the packed add / multiply the compiler forms).
+__device__ __forceinline__ f32x4 swish_l2e(f32x4 u) {
+  f32x4 e, r;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) r[i] = v[i] * sigmoid_fast(v[i]);
-  return r;
+  for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(-u[i]);
+  e = e + 1.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r[i] = __builtin_amdgcn_rcpf(e[i]);
+  return u * r;
 }
 
 // One strip of one (virtual) sample as the pipeline sees it.
@@ -154,6 +164,8 @@ __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
   __syncthreads();
 
   int ring0 = 0;  // ring row of this round's strip row 0: (4 * round) % 10
+  float d_mean = 0.f, d_sd = 1.f;
+  int aff_smp = -1;
   for (;;) {
     if (!cur.valid && !d1.valid && !d2.valid) break;
     // the strip after this one: fetch its input now when it is a different 50-level row
@@ -162,152 +174,169 @@ __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
       else { it_jv = UNI(it_jv + (int)gridDim.x); JOB_START(); }
     }
     const Strip nxt = it;
-    const bool fetch = nxt.valid && tile_on && (!cur.valid || nxt.smp != cur.smp || (nxt.g >> 1) != (cur.g >> 1));
-    if (fetch) load_x(nxt, xn);
+    // Its input row is fetched every round, needed or not (a re-read of the same row hits L2), from inside the block below:
+    // a conditional fetch would be its own basic block, and issued up here it would sit in front of the block's first
+    // vector-memory wait (which the compiler makes a full vmcnt(0)): a round would start by waiting for its own prefetch.
+    const Strip ldx = nxt.valid ? nxt : (cur.valid ? cur : Strip{0, 0, 0, 0});
 
-    // ---------------- P ----------------
-    auto first_layer = [&](auto TY1, f32x4& a0, f32x4& a1) {
-      constexpr int ty1 = decltype(TY1)::value;
-#pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const float xv = xs[s >> 2][s & 3];
-        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[ty1][0][s], xv, a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[ty1][1][s], xv, a1, 0, 0, 0);
-      }
-    };
-    auto run_p = [&]() {
-      if (!(cur.valid && tile_on)) return;
-      f32x4 a0 = bA[0], a1 = bA[1];
-      if (cur.g & 1) first_layer(std::integral_constant<int, 1>{}, a0, a1);
-      else first_layer(std::integral_constant<int, 0>{}, a0, a1);
-      a0 = act32x4(a0, p.act1); a1 = act32x4(a1, p.act1);
-#pragma unroll
-      for (int ty2 = 0; ty2 < 2; ++ty2) {
-        f32x4 b0 = bB, b1 = bB;
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-          const float bv = ks < 4 ? a0[ks & 3] : a1[ks & 3];
-          b0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wB[((2 * ty2) * 8 + ks) * 64], bv, b0, 0, 0, 0);
-          b1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wB[((2 * ty2 + 1) * 8 + ks) * 64], bv, b1, 0, 0, 0);
-        }
-        b0 = act32x4(b0, p.act2); b1 = act32x4(b1, p.act2);
-#pragma unroll
-        for (int tx2 = 0; tx2 < 2; ++tx2) {
-          const f32x4 bs = tx2 ? b1 : b0;
-          f32x4 c0 = bC, c1 = bC;
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wC[i * 64], bs[i], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wC[(4 + i) * 64], bs[i], c1, 0, 0, 0);
-          }
-          c0 = act32x4(c0, p.act3); c1 = act32x4(c1, p.act3);
-          if (px_ok) {
-            int r0 = ring0 + 2 * ty2, r1 = r0 + 1;
-            r0 = r0 >= R_ROWS ? r0 - R_ROWS : r0;
-            r1 = r1 >= R_ROWS ? r1 - R_ROWS : r1;
-            *reinterpret_cast<f32x4*>(smem + r0 * R_ROW + p_off + 2 * tx2 * R_PLANE) = c0;
-            *reinterpret_cast<f32x4*>(smem + r1 * R_ROW + p_off + 2 * tx2 * R_PLANE) = c1;
-          }
-        }
-      }
-    };
-
-    // ---------------- D ----------------
-    // Row q of this wave.  q == 0: row 3 of the strip issued two rounds ago (its lower neighbour is row 0 of last round's
-    // strip, or the zero row at the bottom of the image); q = 1..3: row q-1 of last round's strip.
-    auto run_d = [&]() {
-      int smp, yl;                       // output row (sample, local row)
-      int ro0, ro1, ro2;                 // ring byte offsets of the three window rows
-      const int base = ring0 + 2 * R_ROWS - 4;   // ring row of last round's strip row 0, + R_ROWS so that differences stay positive
-      bool on;
+    // ---- D bookkeeping (scalar unit).  Row q of this wave: q == 0 is row 3 of the strip issued two rounds ago (its lower
+    // neighbour is row 0 of last round's strip, or the zero row at the bottom of the image); q = 1..3 is row q-1 of last
+    // round's strip. ----
+    int d_smp, d_yl, ro0, ro1, ro2;      // output row (sample, local row); ring byte offsets of the three window rows
+    bool d_on;
+    {
+      const int base = ring0 + 2 * R_ROWS - 4;   // ring row of last round's strip row 0 (+ 2 R_ROWS: differences stay positive)
       if (dq == 0) {
         const bool below = d1.valid && d1.smp == d2.smp && d1.g == d2.g + 1;
-        on = d2.valid && (below || d2.g == SH - 1);
-        smp = d2.smp; yl = 4 * d2.g + 3;
+        d_on = d2.valid && (below || d2.g == SH - 1);
+        d_smp = d2.smp; d_yl = 4 * d2.g + 3;
         ro0 = ((base - 2) % R_ROWS) * R_ROW;
         ro1 = ((base - 1) % R_ROWS) * R_ROW;
         ro2 = below ? (base % R_ROWS) * R_ROW : R_ZROW;
       } else {
-        on = d1.valid && !d1.warm;
-        smp = d1.smp; yl = 4 * d1.g + dq - 1;
+        d_on = d1.valid && !d1.warm;
+        d_smp = d1.smp; d_yl = 4 * d1.g + dq - 1;
         const bool above = dq > 1 || (d2.valid && d2.smp == d1.smp && d2.g + 1 == d1.g);   // else: top of the image
         ro0 = above ? ((base + dq - 2) % R_ROWS) * R_ROW : R_ZROW;
         ro1 = ((base + dq - 1) % R_ROWS) * R_ROW;
         ro2 = ((base + dq) % R_ROWS) * R_ROW;
       }
-      if (!on || !d_lane) return;
+      if (!d_on) { d_smp = 0; d_yl = 0; }
+    }
+    // de-standardisation scalars: (re)read on the scalar unit only when the sample changes
+    if (p.aff_out && d_on && d_smp != aff_smp) {
+      typedef const __attribute__((address_space(4))) float* cfp;
+      cfp ap = (cfp)(uintptr_t)(p.aff_out + 2 * (size_t)d_smp);
+      d_mean = ap[0]; d_sd = ap[1];
+      aff_smp = d_smp;
+    }
+    const bool p_on = cur.valid && tile_on;
+    int prow[4];                         // ring byte offsets of the four rows this round's strip writes
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const int r = ring0 + j; prow[j] = (r >= R_ROWS ? r - R_ROWS : r) * R_ROW; }
+
+    // ================= one straight-line block: the first layer's 32 MFMAs run beside the output conv's vector work ==========
+    f32x4 a0 = bA[0], a1 = bA[1];
+    f32x2 acc[4];
+    {
       const float cbias = reinterpret_cast<const float*>(smem + R_WC)[72];
-      f32x2 acc[4];
 #pragma unroll
       for (int o = 0; o < 4; ++o) acc[o] = f32x2{cbias, 0.f};
-      auto window_row = [&](auto DY, const int ro) {
-        constexpr int dy = decltype(DY)::value;
-        const char* rowp = smem + ro;
-        f32x4 lo[6], hi[6];                 // window columns X0 - 1 .. X0 + 4 of this row
+    }
+    auto layer1 = [&](auto TY1, auto S0, auto S1) {   // k-steps [S0, S1) of first-layer tap row TY1
+      constexpr int ty1 = decltype(TY1)::value;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) {
-          const char* gp = rowp + (j == 0 ? d_l : (j == 5 ? d_r : d_c + (j - 1) * R_PLANE));
-          lo[j] = *reinterpret_cast<const f32x4*>(gp);
-          hi[j] = *reinterpret_cast<const f32x4*>(gp + R_HALF);
+      for (int s = decltype(S0)::value; s < decltype(S1)::value; ++s) {
+        const float xv = xs[s >> 2][s & 3];
+        a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[ty1][0][s], xv, a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[ty1][1][s], xv, a1, 0, 0, 0);
+      }
+    };
+    auto window_row = [&](auto DY, const int ro) {
+      constexpr int dy = decltype(DY)::value;
+      const char* rowp = smem + ro;
+      f32x4 lo[6], hi[6];                 // window columns X0 - 1 .. X0 + 4 of this row
+#pragma unroll
+      for (int j = 0; j < 6; ++j) {
+        const char* gp = rowp + (j == 0 ? d_l : (j == 5 ? d_r : d_c + (j - 1) * R_PLANE));
+        lo[j] = *reinterpret_cast<const f32x4*>(gp);
+        hi[j] = *reinterpret_cast<const f32x4*>(gp + R_HALF);
+      }
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const f32x4 wl = wk[(dy * 3 + dx) * 2], wh = wk[(dy * 3 + dx) * 2 + 1];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+          const int j = o + dx;           // column X0 + o + (dx - 1)
+          acc[o] = __builtin_elementwise_fma(f32x2{lo[j][0], lo[j][1]}, f32x2{wl[0], wl[1]}, acc[o]);
+          acc[o] = __builtin_elementwise_fma(f32x2{lo[j][2], lo[j][3]}, f32x2{wl[2], wl[3]}, acc[o]);
+          acc[o] = __builtin_elementwise_fma(f32x2{hi[j][0], hi[j][1]}, f32x2{wh[0], wh[1]}, acc[o]);
+          acc[o] = __builtin_elementwise_fma(f32x2{hi[j][2], hi[j][3]}, f32x2{wh[2], wh[3]}, acc[o]);
         }
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) {
-          const f32x4 wl = wk[(dy * 3 + dx) * 2], wh = wk[(dy * 3 + dx) * 2 + 1];
-#pragma unroll
-          for (int o = 0; o < 4; ++o) {
-            const int j = o + dx;           // column X0 + o + (dx - 1)
-            acc[o] = __builtin_elementwise_fma(f32x2{lo[j][0], lo[j][1]}, f32x2{wl[0], wl[1]}, acc[o]);
-            acc[o] = __builtin_elementwise_fma(f32x2{lo[j][2], lo[j][3]}, f32x2{wl[2], wl[3]}, acc[o]);
-            acc[o] = __builtin_elementwise_fma(f32x2{hi[j][0], hi[j][1]}, f32x2{wh[0], wh[1]}, acc[o]);
-            acc[o] = __builtin_elementwise_fma(f32x2{hi[j][2], hi[j][3]}, f32x2{wh[2], wh[3]}, acc[o]);
-          }
-        }
-        // one window row (48 + 24 registers) in flight at a time: left alone the compiler issues all 54 LDS reads of the
-        // three rows first (216 registers) and spills the resident first-layer weights
-        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : : "memory");
-      };
+      }
+      // one window row (48 + 24 registers) in flight at a time: left alone the compiler issues all 54 LDS reads of the
+      // three rows first (216 registers) and spills the resident first-layer weights
+      asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) : : "memory");
+    };
+    // the first layer's MFMAs between the three window rows of the output conv (one copy of the block per tap row: selecting
+    // the weights per k-step instead costs 32 vector instructions per item)
+    auto front = [&](auto TY1) {
+      layer1(TY1, std::integral_constant<int, 0>{}, std::integral_constant<int, 6>{});
       window_row(std::integral_constant<int, 0>{}, ro0);
+      load_x(ldx, xn);   // behind the asm of window_row (a memory clobber): cannot be hoisted above the first MFMA
+      layer1(TY1, std::integral_constant<int, 6>{}, std::integral_constant<int, 11>{});
       window_row(std::integral_constant<int, 1>{}, ro1);
+      layer1(TY1, std::integral_constant<int, 11>{}, std::integral_constant<int, 16>{});
       window_row(std::integral_constant<int, 2>{}, ro2);
-      float mean = 0.f, sd = 1.f;
-      if (p.aff_out) { mean = p.aff_out[2 * smp]; sd = p.aff_out[2 * smp + 1]; }
+    };
+    if (cur.g & 1) front(std::integral_constant<int, 1>{});
+    else front(std::integral_constant<int, 0>{});
+    {
       float v[4];
+      const bool st_on = d_on && d_lane;
 #pragma unroll
       for (int o = 0; o < 4; ++o) {
-        float t = act32(acc[o][0] + acc[o][1], p.act4);
-        if (p.aff_out) t = __fadd_rn(__fmul_rn(t, sd), mean);
+        float t = acc[o][0] + acc[o][1];
+        if (p.aff_out) t = __fadd_rn(__fmul_rn(t, d_sd), d_mean);
         if (p.nan_guard) {
-          const bool bad = !(fabsf(t) <= 3.402823466e38f);
+          const bool bad = st_on && !(fabsf(t) <= 3.402823466e38f);
           bad_total += (unsigned)__popcll(__ballot(bad));
           t = bad ? 0.f : t;
         }
         v[o] = t;
       }
-      const size_t o0 = ((size_t)smp * OHs + yl) * OW + 4 * db;
-      if (OUT == 0) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o0) = f32x4{v[0], v[1], v[2], v[3]};
-      else {
-        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-        typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
-        const f32x4 vv = {v[0], v[1], v[2], v[3]};
-        uint2 pk;
-        if (OUT == 1) pk = __builtin_bit_cast(uint2, __builtin_convertvector(vv, bf16x4));
-        else pk = __builtin_bit_cast(uint2, __builtin_convertvector(vv, h16x4));
-        *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + o0) = pk;
+      const size_t o0 = ((size_t)d_smp * OHs + d_yl) * OW + 4 * (d_lane ? db : 0);
+      if (st_on) {
+        if (OUT == 0) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o0) = f32x4{v[0], v[1], v[2], v[3]};
+        else {
+          typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+          typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+          const f32x4 vv = {v[0], v[1], v[2], v[3]};
+          uint2 pk;
+          if (OUT == 1) pk = __builtin_bit_cast(uint2, __builtin_convertvector(vv, bf16x4));
+          else pk = __builtin_bit_cast(uint2, __builtin_convertvector(vv, h16x4));
+          *reinterpret_cast<uint2*>(reinterpret_cast<uint16_t*>(p.out) + o0) = pk;
+        }
       }
-    };
-
-    // one copy of each phase in the code; waves 4-7 take them in the other order
-#pragma nounroll
-    for (int ph = 0; ph < 2; ++ph) {
-      if ((ph == 0) == (wave < 4)) run_p();
-      else run_d();
+    }
+    // ---- the rest of the chain: second layer (both tap rows), third layer; the activation of one tile runs beside the
+    // matrix work of the next (independent) one ----
+    a0 = swish_l2e(a0); a1 = swish_l2e(a1);
+    f32x4 b[2][2];
+#pragma unroll
+    for (int ty2 = 0; ty2 < 2; ++ty2) {
+      b[ty2][0] = bB; b[ty2][1] = bB;
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const float bv = ks < 4 ? a0[ks & 3] : a1[ks & 3];
+        b[ty2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wB[((2 * ty2) * 8 + ks) * 64], bv, b[ty2][0], 0, 0, 0);
+        b[ty2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wB[((2 * ty2 + 1) * 8 + ks) * 64], bv, b[ty2][1], 0, 0, 0);
+      }
+    }
+    const int st_sel = (px_ok && p_on) ? 0 : 1;   // lanes / rounds with nothing to store write a dump granule instead (no branch)
+#pragma unroll
+    for (int ty2 = 0; ty2 < 2; ++ty2) {
+      b[ty2][0] = swish_l2e(b[ty2][0]); b[ty2][1] = swish_l2e(b[ty2][1]);
+#pragma unroll
+      for (int tx2 = 0; tx2 < 2; ++tx2) {
+        const f32x4 bs = b[ty2][tx2];
+        f32x4 c0 = bC, c1 = bC;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wC[i * 64], bs[i], c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wC[(4 + i) * 64], bs[i], c1, 0, 0, 0);
+        }
+        c0 = swish_l2e(c0); c1 = swish_l2e(c1);
+        const int o_a = st_sel ? R_DUMP + lane * 16 : prow[2 * ty2] + p_off + 2 * tx2 * R_PLANE;
+        const int o_b = st_sel ? R_DUMP + lane * 16 : prow[2 * ty2 + 1] + p_off + 2 * tx2 * R_PLANE;
+        *reinterpret_cast<f32x4*>(smem + o_a) = c0;
+        *reinterpret_cast<f32x4*>(smem + o_b) = c1;
+      }
     }
 
     lds_barrier32();
-    if (fetch) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) xs[q] = xn[q];
-    }
+    for (int q = 0; q < 4; ++q) xs[q] = xn[q];
     d2 = d1; d1 = cur; cur = nxt;
     ring0 += 4;
     ring0 = ring0 >= R_ROWS ? ring0 - R_ROWS : ring0;

@@ -212,20 +212,81 @@ def test_verbose_call_prints_the_reference_style_report_and_same_fields(srcfd, d
 
 @pytest.mark.gpu
 def test_tiled_sr_config5(srcfd, oracle, enc_weights, dec_weights):
-    """40x40x3 -> 1600x1600x3 through 4x4 tiles (BASELINE config 5), f16 operands."""
+    """40x40x3 -> 1600x1600x3 through 4x4 tiles (BASELINE config 5), f16 operands: every one of the 48 tile samples of the
+    stitched field equals the per-tile predict bit for bit (tiling = slicing + independent samples, nothing else), and
+    tiles in three different corners / components match the float64 oracle."""
     require_gpu(srcfd)
     pl = importlib.import_module("sr-for-cfd_amd.pipeline")
     rng = np.random.default_rng(9)
     field = rng.standard_normal((40, 40, 3)).astype(np.float32)
+    lr, hr = srcfd.load_stats(STATS_TXT, 10, 400)
+    ain = np.array([lr[c] for c in "uvp"], np.float32)
+    aout = np.array([hr[c] for c in "uvp"], np.float32)
+    field = field * ain[:, 1] + ain[:, 0]
     m = srcfd.SRModel.from_weights(enc_weights, dec_weights, device=0)
     m.precision = "f16"
-    y = pl.tiled_super_resolution(field, m, lr_dim=10)
-    assert y.shape == (1600, 1600, 3)
-    # tile (1,2), component 1 against the oracle
-    t = field[10:20, 20:30, 1][None, ..., None]
-    ref = oracle.superres_forward(t, enc_weights, dec_weights, np.float64)[0, ..., 0]
-    got = y[400:800, 800:1200, 1]
-    assert oracle.rel_l2(got[None], ref[None]) <= 3e-3
+    y = pl.tiled_super_resolution(field, m, lr_dim=10, in_affine=ain, out_affine=aout)
+    assert y.shape == (1600, 1600, 3) and np.isfinite(y).all()
+    for ty in range(4):
+        for tx in range(4):
+            for c in range(3):
+                t = np.ascontiguousarray(field[10 * ty:10 * ty + 10, 10 * tx:10 * tx + 10, c])[None, ..., None]
+                one = m.predict(t, in_affine=ain[c:c + 1], out_affine=aout[c:c + 1])[0, ..., 0]
+                np.testing.assert_array_equal(y[400 * ty:400 * ty + 400, 400 * tx:400 * tx + 400, c], one)
+    for ty, tx, c in ((1, 2, 1), (0, 0, 0), (3, 3, 2), (2, 0, 1)):
+        t = field[10 * ty:10 * ty + 10, 10 * tx:10 * tx + 10, c][None, ..., None]
+        ts = ((t - ain[c, 0]) / ain[c, 1]).astype(np.float32)
+        ref = oracle.superres_forward(ts, enc_weights, dec_weights, np.float64)[0, ..., 0]
+        got = (y[400 * ty:400 * ty + 400, 400 * tx:400 * tx + 400, c] - aout[c, 0]) / aout[c, 1]
+        assert oracle.rel_l2(got[None], ref[None]) <= 3e-3, (ty, tx, c)
+
+
+@pytest.mark.gpu
+def test_two_handles_on_two_threads(srcfd, enc_weights, dec_weights):
+    """The ABI's threading contract (include/srcfd.h; SURVEY.md 8b "threading"): distinct handles may be driven from distinct
+    threads at the same time (ctypes drops the GIL around every call), and srcfd_last_error() is per thread -- each thread
+    reads the message of ITS failed call, whatever the other thread did in between."""
+    import threading
+    require_gpu(srcfd)
+    L = importlib.import_module("sr-for-cfd_amd._lib")
+    rng = np.random.default_rng(21)
+    xs = [rng.standard_normal((5 + 3 * i, 10, 10, 1)).astype(np.float32) for i in range(2)]
+    models = [srcfd.SRModel.from_weights(enc_weights, dec_weights, device=0) for _ in range(2)]
+    models[0].precision, models[1].precision = "bf16", "fp32"
+    want = [m.predict(x) for m, x in zip(models, xs)]              # single-threaded results
+    got, errs, msgs = [None, None], [None, None], [None, None]
+    gate = threading.Barrier(2)
+
+    def work(i):
+        try:
+            gate.wait()
+            for _ in range(12):                                     # overlapping forward passes on the two handles
+                y = models[i].predict(xs[i])
+            got[i] = y
+            gate.wait()
+            # a failing call per thread, interleaved: 0 fails, 1 fails, then each reads its own message
+            if i == 0:
+                rc = L.lib.srcfd_model_set_precision(models[0]._h, 99)
+                gate.wait(); gate.wait()
+            else:
+                gate.wait()
+                rc = L.lib.srcfd_predict(models[1]._h, None, -3, None, None, None, 0, None)
+                gate.wait()
+            assert rc != 0
+            msgs[i] = L.last_error()
+        except Exception as e:   # noqa: BLE001 - reported below
+            errs[i] = e
+            gate.abort()
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert errs == [None, None], errs
+    np.testing.assert_array_equal(got[0], want[0])
+    np.testing.assert_array_equal(got[1], want[1])
+    assert "precision" in msgs[0] and "precision" not in msgs[1] and msgs[1], msgs
 
 
 LDC_BC = {"u": {"left": ("dirichlet", 0.0), "right": ("dirichlet", 0.0), "top": ("dirichlet", 1.0), "bottom": ("dirichlet", 0.0)},

@@ -341,8 +341,8 @@ def test_chained_transposed_convolutions(srcfd, oracle, chain, monkeypatch):
     m.predict(x)
     names = [nm for nm, _ in m.get_profile()]
     m.set_profiling(False)
-    # the 64 -> 32 -> 16 -> 8 chain followed by the 3x3 output conv is the streaming tail32 kernel (4 layers, one launch)
-    assert sum("+" in nm for nm in names) == 1 and max(nm.count("+") for nm in names) == (3 if len(chain) == 4 else 1), names
+    # (with a linear last ConvT these chains are not the all-swish pattern of the streaming tail32 kernel, which has its own test)
+    assert sum("+" in nm for nm in names) == 1 and max(nm.count("+") for nm in names) == len(chain) - 2, names
     m.precision = "fp32_naive"
     assert oracle.rel_l2(m.predict(x), ref) <= TOL_FP32
     # a batch that is not the first in its buffer: rows of a bigger batch equal the small batch's (per-pixel independence)
