@@ -305,7 +305,8 @@ int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, cons
     int cur = 0;
     rc = m.launch("conv2d", s, [&] { return launch_enc_conv1_16(f16, xin, ain, fs->d_f32 + fs->c1w_off, fs->d_f32 + fs->c1b_off, fs->act[0], c, s); });
     if (rc) return rc;
-    static const bool use_mid = [] { const char* e = getenv("SRCFD_MID"); return !e || atoi(e) != 0; }();  // 0: generic GEMMs (A/B, tests)
+    // functional A/B switch of the tests (both implementations of the network's middle are complete): read per call
+    const bool use_mid = [] { const char* e = getenv("SRCFD_MID"); return !e || atoi(e) != 0; }();  // 0: generic GEMMs (A/B, tests)
     int prev_layer = -1;
     for (const Op16& o : fs->ops) {
       if (use_mid && o.layer >= 5) break;  // ConvT#0 / ConvT#1 run in the fused mid kernel below
