@@ -219,6 +219,27 @@ int srcfd_predict_into_solver_state(srcfd_model* m, srcfd_resampler* r, const fl
                                     const float* out_affine, const srcfd_solver_bc bc[3], double* Var, int flags,
                                     int64_t* n_nonfinite);
 
+/* ---- coarse-mesh solver (the producer of the SR call's input) ------------------------------------
+ * Replaces, for the lid-driven cavity, `CFDSolver(mesh, fluid, settings, bc).solve()` as `run_coarse_simulation` uses it
+ * (PyCFD_ML_accelerated.py:694-761; kernels :110-328, time loop :396-505): float64, host.  bc_type / bc_value are
+ * apply_bc_configured's arrays per variable (u, v, p), order left, right, top, bottom; 0 = Dirichlet, 1 = Neumann
+ * (`_get_bc_arrays`, :352-375).  var_out receives the solver state Var (3, nx+2, ny+2) including ghost cells; the
+ * coarse fields the SR call takes are Var[k, 1:-1, 1:-1].T (:755-759).  Returns SRCFD_EINVAL with a message when the
+ * residuals turn NaN / Inf (the reference raises ValueError, :487-492). */
+#define SRCFD_SCHEME_QUICK 0
+#define SRCFD_SCHEME_UPWIND 1
+typedef struct srcfd_coarse_problem {
+  int nx, ny;
+  double lx, ly;
+  double reynolds, rho, dt;
+  int scheme;                /* SRCFD_SCHEME_* */
+  int max_iterations;
+  double tolerance[3];       /* convergence_criteria u, v, p on rms / dt */
+  int bc_type[3][4];
+  double bc_value[3][4];
+} srcfd_coarse_problem;
+int srcfd_coarse_solve(const srcfd_coarse_problem* problem, double* var_out, int* iterations, double rms[3]);
+
 /* ---- training -----------------------------------------------------------
  * One optimisation step of SuperResolutionAE, split so that a data-parallel driver can put its
  * gradient all-reduce between the two halves (one flat f32 buffer per step).

@@ -39,6 +39,13 @@ class Layer(C.Structure):
     ]
 
 
+class CoarseProblem(C.Structure):
+    _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("lx", C.c_double), ("ly", C.c_double),
+                ("reynolds", C.c_double), ("rho", C.c_double), ("dt", C.c_double),
+                ("scheme", C.c_int), ("max_iterations", C.c_int), ("tolerance", C.c_double * 3),
+                ("bc_type", (C.c_int * 4) * 3), ("bc_value", (C.c_double * 4) * 3)]
+
+
 class SolverBC(C.Structure):
     _fields_ = [("type", C.c_int * 4), ("value", C.c_double * 4), ("left_profile", C.POINTER(C.c_double))]
 
@@ -103,6 +110,7 @@ _protos = {
     "srcfd_trainer_num_params": (C.c_int64, [_p]),
     "srcfd_trainer_get_params": (C.c_int, [_p, _p]),
     "srcfd_trainer_forward_backward": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_float, _p, _p, _p]),
+    "srcfd_coarse_solve": (C.c_int, [C.POINTER(CoarseProblem), _p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "srcfd_adam_step": (C.c_int, [_p, _p, _p, _p, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, _p]),
     "srcfd_stats_load": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_double)]),
     "srcfd_stats_save": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_double)]),

@@ -173,6 +173,28 @@ def test_harness_ldc_matches_oracle(srcfd, oracle, enc_weights, dec_weights, dec
 
 
 @pytest.mark.gpu
+def test_config1_ldc_re400_from_our_coarse_solver(srcfd, oracle, enc_weights, dec_weights, decoder_h5):
+    """BASELINE config 1 end to end: the coarse 10x10 double-lid field at Re = 400 from this repo's coarse solver (the
+    reference checkout has none), through `ml_super_resolution` exactly as PyCFD_ML_accelerated.py:1425-1445 calls it, f32."""
+    require_gpu(srcfd)
+    from conftest import COARSE_RE400, GOLDEN
+    pl = importlib.import_module("sr-for-cfd_amd.pipeline")
+    co = importlib.import_module("sr-for-cfd_amd.coarse")
+    fresh = co.run_coarse_simulation(400.0, 10, bc=co.LDC_DOUBLE_LID)
+    stored = srcfd.read_coarse_fields(os.path.join(GOLDEN, COARSE_RE400))
+    for c in "uvp":
+        np.testing.assert_array_equal(fresh[c], stored[c])
+    out = pl.ml_super_resolution(fresh, 10, 400, STATS_TXT, ENCODER_H5, decoder_h5)
+    ref = oracle.ml_super_resolution(fresh, 10, 400, oracle.parse_stats(STATS_TXT), enc_weights, dec_weights,
+                                     dtype=np.float32, net_dtype=np.float64)
+    _, hr = srcfd.load_stats(STATS_TXT, 10, 400)
+    for c in "uvp":
+        assert out[c].shape == (400, 400) and np.isfinite(out[c]).all()
+        a, b = (out[c] - hr[c][0]) / hr[c][1], (ref[c] - hr[c][0]) / hr[c][1]
+        assert oracle.rel_l2(a[None], b[None]) <= 1e-5
+
+
+@pytest.mark.gpu
 def test_harness_bfs_with_resampling_and_blend_matches_reference_recipe(srcfd, oracle, enc_weights, dec_weights, decoder_h5, coarse_cases):
     """BASELINE config 3: BFS Re400 coarse field, aspect-ratio correction (lx=10, ly=3) and
     adaptive normalisation (blend 0.3), bfs_ml_accelerated.py:1473 call."""
