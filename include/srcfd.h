@@ -183,6 +183,13 @@ int srcfd_h5w_save(srcfd_h5w* w, const char* path);
 /* Saves the handle's weights as legacy Keras-H5 sub-model files
  * (sr-ae-conv.ipynb:c584-585); split_at = index of the first decoder layer. */
 int srcfd_model_save_h5(const srcfd_model* m, const char* encoder_h5, const char* decoder_h5);
+/* The whole-model file `superres_model.save("superres_{lr}to{hr}_vanilla_ae_{suffix}.h5")` (sr-ae-conv.ipynb:c586):
+ * encoder and decoder in ONE legacy Keras-H5 file (groups model_weights/<sub-model>/<layer>/{kernel,bias}, the layout
+ * Keras 3.8 writes for a subclassed Model; unpinned -- the reference's superres files are absent, .MISSING_LARGE_BLOBS:29-31).
+ * Loading takes the architecture from the nested sub-model configs when the file carries them and otherwise assumes the
+ * reference's encoder_10 / decoder_400 definition (sr-ae-conv.ipynb:c162-169, c277-287). */
+int srcfd_model_save_superres_h5(const srcfd_model* m, const char* superres_h5);
+int srcfd_model_load_superres_h5(const char* superres_h5, int device, srcfd_model** out);
 
 /* ---- device-side resampling of the SR output (BFS aspect-ratio correction) -------------------
  * Replaces `reshape_square_to_rectangular` (bfs_ml_accelerated.py:104-145): per component

@@ -607,6 +607,34 @@ int srcfd_model_load_h5(const char* encoder_h5, const char* decoder_h5, int devi
   return srcfd::finish_create(m, out);
 }
 
+int srcfd_model_load_superres_h5(const char* superres_h5, int device, srcfd_model** out) {
+  if (!out || !superres_h5) { set_error("srcfd_model_load_superres_h5: bad arguments"); return SRCFD_EINVAL; }
+  *out = nullptr;
+  std::unique_ptr<Model> m(new Model());
+  m->device = device;
+  try {
+    srcfd::append_h5_whole(m->desc, superres_h5);
+  } catch (const srcfd::FileError& e) {
+    set_error(e.msg);
+    return e.code;
+  } catch (const std::exception& e) {
+    set_error(e.what());
+    return SRCFD_EIO;
+  }
+  return srcfd::finish_create(m, out);
+}
+
+int srcfd_model_save_superres_h5(const srcfd_model* m, const char* superres_h5) {
+  if (!m || !superres_h5) { set_error("srcfd_model_save_superres_h5: bad arguments"); return SRCFD_EINVAL; }
+  try {
+    srcfd::save_h5_whole(M(m)->desc, superres_h5);
+  } catch (const srcfd::FileError& e) {
+    set_error(e.msg);
+    return e.code;
+  }
+  return SRCFD_OK;
+}
+
 int srcfd_model_create(const srcfd_layer* layers, int n_layers, const int in_shape[3], int device, srcfd_model** out) {
   if (!out || !layers || n_layers <= 0 || !in_shape) { set_error("srcfd_model_create: bad arguments"); return SRCFD_EINVAL; }
   *out = nullptr;

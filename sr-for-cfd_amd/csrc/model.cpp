@@ -143,25 +143,12 @@ static std::string activation_of(const jsonmin::Value& cfg) {
   throw std::runtime_error("unparseable activation");
 }
 
-void append_h5_submodel(ModelDesc& m, const std::string& path) {
-  {
-    FILE* f = std::fopen(path.c_str(), "rb");
-    if (!f) throw FileError{SRCFD_ENOENT, "model file '" + path + "' not found"};
-    std::fclose(f);
-  }
-  try {
-    auto file = h5lite::File::open(path);
-    const h5lite::Attr* cfg = file->root()->attr("model_config");
-    if (!cfg || cfg->strings.empty()) throw std::runtime_error("no model_config attribute (not a legacy Keras .h5 model)");
-    jsonmin::Value root = jsonmin::parse(cfg->strings[0]);
-    const std::string cls = root.at("class_name").str;
-    if (cls != "Functional" && cls != "Sequential" && cls != "Model") throw std::runtime_error("model class '" + cls + "' unsupported");
-    const jsonmin::Value& mc = root.at("config");
+// Appends the layers of ONE sub-model described by a Functional / Sequential config `mc`; `mw` is the group its weights hang
+// under (`nested`: the whole-model layout, see append_h5_whole).
+static void parse_submodel(ModelDesc& m, const jsonmin::Value& mc, h5lite::File* file, h5lite::Node* mw, bool nested) {
     SubModel sub;
     sub.name = mc.get("name") ? mc.at("name").str : "model";
     sub.first = (int)m.layers.size();
-    h5lite::Node* mw = file->find("model_weights");
-    if (!mw) throw std::runtime_error("no model_weights group");
     int sub_in[3] = {0, 0, 0};
     for (auto& lj : mc.at("layers").arr) {
       const std::string lc = lj.at("class_name").str;
@@ -209,10 +196,18 @@ void append_h5_submodel(ModelDesc& m, const std::string& path) {
         for (int i = 0; i < 3; ++i) L.reshape[i] = t[i];
       } else throw std::runtime_error("layer class '" + lc + "' unsupported");
       if (has_w) {
-        h5lite::Node* lg = mw->child(lname);
+        // sub-model file: model_weights/<layer> holds weight_names "<layer>/kernel", ... relative to itself; whole-model
+        // file: model_weights/<sub-model> holds the names of all its layers' weights, the same relative paths
+        h5lite::Node* lg = nested ? mw : mw->child(lname);
         if (!lg) throw std::runtime_error("model_weights/" + lname + " missing");
-        const h5lite::Attr* wn = lg->attr("weight_names");
-        if (!wn || wn->strings.empty()) throw std::runtime_error("layer '" + lname + "' has no weight_names");
+        const h5lite::Attr* wn_all = lg->attr("weight_names");
+        if (!wn_all || wn_all->strings.empty()) throw std::runtime_error("layer '" + lname + "' has no weight_names");
+        h5lite::Attr wn_own;
+        if (nested) {
+          for (auto& nm : wn_all->strings) if (nm.rfind(lname + "/", 0) == 0) wn_own.strings.push_back(nm);
+          if (wn_own.strings.empty()) throw std::runtime_error("layer '" + lname + "' has no weights in its sub-model's weight_names");
+        }
+        const h5lite::Attr* wn = nested ? &wn_own : wn_all;
         bool use_bias = true;
         if (const auto* ub = c.get("use_bias")) use_bias = ub->kind != jsonmin::Value::Bool || ub->b;
         if (wn->strings.size() != (use_bias ? 2u : 1u)) throw std::runtime_error("layer '" + lname + "': unexpected weight count");
@@ -261,6 +256,24 @@ void append_h5_submodel(ModelDesc& m, const std::string& path) {
                                  " inputs but the preceding model yields " + std::to_string(prev[0] * prev[1] * prev[2]));
     }
     m.subs.push_back(sub);
+}
+
+void append_h5_submodel(ModelDesc& m, const std::string& path) {
+  {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) throw FileError{SRCFD_ENOENT, "model file '" + path + "' not found"};
+    std::fclose(f);
+  }
+  try {
+    auto file = h5lite::File::open(path);
+    const h5lite::Attr* cfg = file->root()->attr("model_config");
+    if (!cfg || cfg->strings.empty()) throw std::runtime_error("no model_config attribute (not a legacy Keras .h5 model)");
+    jsonmin::Value root = jsonmin::parse(cfg->strings[0]);
+    const std::string cls = root.at("class_name").str;
+    if (cls != "Functional" && cls != "Sequential" && cls != "Model") throw std::runtime_error("model class '" + cls + "' unsupported");
+    h5lite::Node* mw = file->find("model_weights");
+    if (!mw) throw std::runtime_error("no model_weights group");
+    parse_submodel(m, root.at("config"), file.get(), mw, false);
     m.infer_shapes();
   } catch (const FileError&) {
     throw;
@@ -308,29 +321,44 @@ static std::string layer_json(const Layer& L, const std::string& prev_name, bool
   return o.str();
 }
 
+// {"name": ..., "trainable": true, "layers": [...], "input_layers": ..., "output_layers": ...} of sub-model si
+static std::string submodel_config_json(const ModelDesc& m, int si, std::vector<std::string>* layer_names_out) {
+  const SubModel& sub = m.subs[si];
+  const Layer& first = m.layers[sub.first];
+  bool flat_in = first.in_shape[0] == 1 && first.in_shape[1] == 1 && first.kind == SRCFD_LAYER_DENSE;
+  std::ostringstream cfg;
+  cfg << "{\"name\": \"" << sub.name << "\", \"trainable\": true, \"layers\": [";
+  cfg << "{\"class_name\": \"InputLayer\", \"config\": {\"batch_shape\": " << shape_json(first.in_shape, flat_in)
+      << ", \"dtype\": \"float32\", \"sparse\": false, \"name\": \"" << sub.input_name << "\"}, \"name\": \"" << sub.input_name
+      << "\", \"inbound_nodes\": []}";
+  std::string prev = sub.input_name;
+  bool flat = flat_in;
+  if (layer_names_out) layer_names_out->push_back(sub.input_name);
+  for (int i = 0; i < sub.count; ++i) {
+    const Layer& L = m.layers[sub.first + i];
+    cfg << ", " << layer_json(L, prev, flat);
+    prev = L.name;
+    flat = L.kind == SRCFD_LAYER_DENSE || L.kind == SRCFD_LAYER_FLATTEN;
+    if (layer_names_out) layer_names_out->push_back(L.name);
+  }
+  cfg << "], \"input_layers\": [[\"" << sub.input_name << "\", 0, 0]], \"output_layers\": [[\"" << prev << "\", 0, 0]]}";
+  return cfg.str();
+}
+
+static std::vector<uint64_t> kernel_dims(const Layer& L) {
+  if (L.kind == SRCFD_LAYER_DENSE) return {(uint64_t)L.cin, (uint64_t)L.cout};
+  if (L.kind == SRCFD_LAYER_CONV2D) return {(uint64_t)L.kh, (uint64_t)L.kw, (uint64_t)L.cin, (uint64_t)L.cout};
+  return {(uint64_t)L.kh, (uint64_t)L.kw, (uint64_t)L.cout, (uint64_t)L.cin};
+}
+
 void save_h5_submodel(const ModelDesc& m, int si, const std::string& path) {
   if (si < 0 || si >= (int)m.subs.size()) throw FileError{SRCFD_EINVAL, "no such sub-model"};
   const SubModel& sub = m.subs[si];
   try {
     auto f = h5lite::File::create();
-    const Layer& first = m.layers[sub.first];
-    bool flat_in = first.in_shape[0] == 1 && first.in_shape[1] == 1 && first.kind == SRCFD_LAYER_DENSE;
+    std::vector<std::string> layer_names;
     std::ostringstream cfg;
-    cfg << "{\"class_name\": \"Functional\", \"config\": {\"name\": \"" << sub.name << "\", \"trainable\": true, \"layers\": [";
-    cfg << "{\"class_name\": \"InputLayer\", \"config\": {\"batch_shape\": " << shape_json(first.in_shape, flat_in)
-        << ", \"dtype\": \"float32\", \"sparse\": false, \"name\": \"" << sub.input_name << "\"}, \"name\": \"" << sub.input_name
-        << "\", \"inbound_nodes\": []}";
-    std::string prev = sub.input_name;
-    bool flat = flat_in;
-    std::vector<std::string> layer_names{sub.input_name};
-    for (int i = 0; i < sub.count; ++i) {
-      const Layer& L = m.layers[sub.first + i];
-      cfg << ", " << layer_json(L, prev, flat);
-      prev = L.name;
-      flat = L.kind == SRCFD_LAYER_DENSE || L.kind == SRCFD_LAYER_FLATTEN;
-      layer_names.push_back(L.name);
-    }
-    cfg << "], \"input_layers\": [[\"" << sub.input_name << "\", 0, 0]], \"output_layers\": [[\"" << prev << "\", 0, 0]]}}";
+    cfg << "{\"class_name\": \"Functional\", \"config\": " << submodel_config_json(m, si, &layer_names) << "}";
 
     auto str_attr = [](const std::vector<std::string>& s, bool scalar, bool utf8) {
       h5lite::Attr a;
@@ -357,10 +385,7 @@ void save_h5_submodel(const ModelDesc& m, int si, const std::string& path) {
       h5lite::Node* g = f->make_group("model_weights/" + L.name);
       if (L.kernel.empty()) { g->attrs.push_back({"weight_names", empty_attr()}); continue; }
       g->attrs.push_back({"weight_names", str_attr({L.name + "/kernel", L.name + "/bias"}, false, false)});
-      std::vector<uint64_t> kd;
-      if (L.kind == SRCFD_LAYER_DENSE) kd = {(uint64_t)L.cin, (uint64_t)L.cout};
-      else if (L.kind == SRCFD_LAYER_CONV2D) kd = {(uint64_t)L.kh, (uint64_t)L.kw, (uint64_t)L.cin, (uint64_t)L.cout};
-      else kd = {(uint64_t)L.kh, (uint64_t)L.kw, (uint64_t)L.cout, (uint64_t)L.cin};
+      const std::vector<uint64_t> kd = kernel_dims(L);
       const std::string base = "model_weights/" + L.name + "/" + L.name + "/";
       f->make_dataset(base + "kernel", h5lite::F32, kd, L.kernel.data());
       f->make_dataset(base + "bias", h5lite::F32, {(uint64_t)L.cout}, L.bias.data());
@@ -370,6 +395,164 @@ void save_h5_submodel(const ModelDesc& m, int si, const std::string& path) {
     throw;
   } catch (const std::exception& e) {
     throw FileError{SRCFD_EIO, "cannot save model '" + path + "': " + e.what()};
+  }
+}
+
+// ---------------------------------------------------------------------------
+// whole-model file: `superres_model.save("superres_{lr}to{hr}_vanilla_ae_{suffix}.h5")` (sr-ae-conv.ipynb:c586)
+//
+// LAYOUT UNPINNED: the reference's three superres_*.h5 files are absent from its checkout (.MISSING_LARGE_BLOBS:29-31) and
+// Keras is not installable here, so this follows what Keras 3.8's legacy-H5 saver (keras/src/legacy/saving/
+// legacy_h5_format.py: save_model_to_hdf5 -> save_weights_to_hdf5_group) does for a subclassed Model whose `layers` are
+// the two Functional sub-models:
+//   /            attrs backend, keras_version, model_config = {"class_name": "SuperResolutionAE", "config": {...}}
+//   /model_weights                      attrs backend, keras_version, layer_names = [<encoder name>, <decoder name>]
+//   /model_weights/<sub-model>          attr  weight_names = ["conv2d/kernel", "conv2d/bias", ...]  (variable paths)
+//   /model_weights/<sub-model>/<layer>/{kernel,bias}
+//   /model_weights/top_level_model_weights   attr weight_names = []
+// The subclass's auto-generated config serialises its constructor arguments, i.e. the two sub-models (`encoder_lr`,
+// `decoder_hr`); the reader takes the architecture from there when present and otherwise assumes the reference's
+// encoder_10 / decoder_400 definition (sr-ae-conv.ipynb:c162-169, c277-287), as `load_weights` into a rebuilt model would.
+// ---------------------------------------------------------------------------
+void save_h5_whole(const ModelDesc& m, const std::string& path) {
+  if (m.subs.size() != 2) throw FileError{SRCFD_EINVAL, "whole-model file needs the encoder + decoder pair"};
+  try {
+    auto f = h5lite::File::create();
+    auto str_attr = [](const std::vector<std::string>& s, bool scalar, bool utf8) {
+      h5lite::Attr a;
+      a.dtype = h5lite::STR; a.scalar = scalar; a.utf8 = utf8; a.strings = s;
+      if (!scalar) a.dims = {s.size()};
+      return a;
+    };
+    auto empty_attr = [] { h5lite::Attr a; a.dtype = h5lite::F64; a.scalar = false; a.dims = {0}; return a; };
+    std::ostringstream cfg;
+    cfg << "{\"class_name\": \"SuperResolutionAE\", \"config\": {\"name\": \"super_resolution_ae\", \"trainable\": true";
+    const char* keys[2] = {"encoder_lr", "decoder_hr"};   // SuperResolutionAE.__init__(encoder_lr, decoder_hr) (sr-ae-conv.ipynb:c290)
+    for (int si = 0; si < 2; ++si)
+      cfg << ", \"" << keys[si] << "\": {\"module\": \"keras\", \"class_name\": \"Functional\", \"config\": " << submodel_config_json(m, si, nullptr)
+          << ", \"registered_name\": \"Functional\"}";
+    cfg << "}}";
+    f->root()->attrs.push_back({"backend", str_attr({"tensorflow"}, true, true)});
+    f->root()->attrs.push_back({"keras_version", str_attr({"3.8.0"}, true, true)});
+    f->root()->attrs.push_back({"model_config", str_attr({cfg.str()}, true, false)});
+    h5lite::Node* mw = f->make_group("model_weights");
+    mw->attrs.push_back({"backend", str_attr({"tensorflow"}, true, false)});
+    mw->attrs.push_back({"keras_version", str_attr({"3.8.0"}, true, false)});
+    mw->attrs.push_back({"layer_names", str_attr({m.subs[0].name, m.subs[1].name}, false, false)});
+    f->make_group("model_weights/top_level_model_weights")->attrs.push_back({"weight_names", empty_attr()});
+    for (int si = 0; si < 2; ++si) {
+      const SubModel& sub = m.subs[si];
+      h5lite::Node* g = f->make_group("model_weights/" + sub.name);
+      std::vector<std::string> names;
+      for (int i = 0; i < sub.count; ++i) {
+        const Layer& L = m.layers[sub.first + i];
+        if (L.kernel.empty()) continue;
+        names.push_back(L.name + "/kernel");
+        names.push_back(L.name + "/bias");
+        const std::string base = "model_weights/" + sub.name + "/" + L.name + "/";
+        f->make_dataset(base + "kernel", h5lite::F32, kernel_dims(L), L.kernel.data());
+        f->make_dataset(base + "bias", h5lite::F32, {(uint64_t)L.cout}, L.bias.data());
+      }
+      g->attrs.push_back({"weight_names", str_attr(names, false, false)});
+    }
+    f->save(path);
+  } catch (const FileError&) {
+    throw;
+  } catch (const std::exception& e) {
+    throw FileError{SRCFD_EIO, "cannot save model '" + path + "': " + e.what()};
+  }
+}
+
+// The reference architecture as Functional configs, for whole-model files whose model_config does not carry the sub-models.
+static std::string reference_submodel_config(const std::string& name, h5lite::Node* g) {
+  auto shape_of = [&](const std::string& layer, const char* what) -> std::vector<uint64_t> {
+    h5lite::Node* l = g->child(layer);
+    h5lite::Node* d = l ? l->child(what) : nullptr;
+    if (!d || d->is_group) throw std::runtime_error("whole-model file: " + name + "/" + layer + "/" + what + " missing");
+    return d->dims;
+  };
+  auto conv = [&](const std::string& ln, const char* cls, int stride, const char* pad, const char* act) {
+    auto kd = shape_of(ln, "kernel");
+    if (kd.size() != 4) throw std::runtime_error("whole-model file: kernel rank of " + ln);
+    const uint64_t filters = std::string(cls) == "Conv2D" ? kd[3] : kd[2];
+    std::ostringstream o;
+    o << "{\"class_name\": \"" << cls << "\", \"config\": {\"name\": \"" << ln << "\", \"filters\": " << filters << ", \"kernel_size\": [" << kd[0] << ", "
+      << kd[1] << "], \"strides\": [" << stride << ", " << stride << "], \"padding\": \"" << pad << "\", \"activation\": \"" << act << "\"}}";
+    return o.str();
+  };
+  auto dense = [&](const std::string& ln, const char* act) {
+    auto kd = shape_of(ln, "kernel");
+    if (kd.size() != 2) throw std::runtime_error("whole-model file: kernel rank of " + ln);
+    std::ostringstream o;
+    o << "{\"class_name\": \"Dense\", \"config\": {\"name\": \"" << ln << "\", \"units\": " << kd[1] << ", \"activation\": \"" << act << "\"}}";
+    return o.str();
+  };
+  std::ostringstream o;
+  o << "{\"name\": \"" << name << "\", \"layers\": [";
+  if (g->child("conv2d") && g->child("latent_vector")) {   // encoder_lr (sr-ae-conv.ipynb:c162-169)
+    const uint64_t lat_in = shape_of("dense", "kernel")[0], c2 = shape_of("conv2d_1", "kernel")[3];
+    const int side2 = (int)std::lround(std::sqrt((double)lat_in / (double)c2));   // conv output side: stride-2 SAME of the input
+    o << "{\"class_name\": \"InputLayer\", \"config\": {\"name\": \"" << name << "_input\", \"batch_shape\": [null, " << 2 * side2 << ", " << 2 * side2 << ", "
+      << shape_of("conv2d", "kernel")[2] << "]}}, " << conv("conv2d", "Conv2D", 2, "same", "swish") << ", " << conv("conv2d_1", "Conv2D", 1, "same", "swish")
+      << ", {\"class_name\": \"Flatten\", \"config\": {\"name\": \"flatten\"}}, " << dense("dense", "swish") << ", " << dense("latent_vector", "linear");
+  } else if (g->child("dense_1") && g->child("conv2d_transpose")) {   // decoder_hr (sr-ae-conv.ipynb:c277-287)
+    const uint64_t units = shape_of("dense_1", "kernel")[1], cin = shape_of("conv2d_transpose", "kernel")[3];
+    const int side = (int)std::lround(std::sqrt((double)units / (double)cin));
+    o << "{\"class_name\": \"InputLayer\", \"config\": {\"name\": \"" << name << "_input\", \"batch_shape\": [null, " << shape_of("dense_1", "kernel")[0] << "]}}, "
+      << dense("dense_1", "swish") << ", {\"class_name\": \"Reshape\", \"config\": {\"name\": \"reshape\", \"target_shape\": [" << side << ", " << side << ", " << cin << "]}}";
+    for (int i = 0;; ++i) {
+      const std::string ln = i == 0 ? "conv2d_transpose" : "conv2d_transpose_" + std::to_string(i);
+      if (!g->child(ln)) break;
+      o << ", " << conv(ln, "Conv2DTranspose", 2, "valid", "swish");
+    }
+    std::string outl;
+    for (auto& c : g->children) if (c.first.rfind("output_image", 0) == 0) outl = c.first;
+    if (outl.empty()) throw std::runtime_error("whole-model file: no output_image_* layer");
+    o << ", " << conv(outl, "Conv2D", 1, "same", "linear");
+  } else throw std::runtime_error("whole-model file: sub-model '" + name + "' is neither the reference encoder nor decoder");
+  o << "]}";
+  return o.str();
+}
+
+void append_h5_whole(ModelDesc& m, const std::string& path) {
+  {
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) throw FileError{SRCFD_ENOENT, "model file '" + path + "' not found"};
+    std::fclose(f);
+  }
+  try {
+    auto file = h5lite::File::open(path);
+    h5lite::Node* mw = file->find("model_weights");
+    if (!mw) throw std::runtime_error("no model_weights group");
+    const h5lite::Attr* ln = mw->attr("layer_names");
+    if (!ln || ln->strings.size() != 2) throw std::runtime_error("not a whole-model file: model_weights/layer_names must name the two sub-models");
+    jsonmin::Value root;
+    bool have_cfg = false;
+    if (const h5lite::Attr* cfg = file->root()->attr("model_config"))
+      if (!cfg->strings.empty()) { root = jsonmin::parse(cfg->strings[0]); have_cfg = true; }
+    for (const std::string& sname : ln->strings) {
+      h5lite::Node* g = mw->child(sname);
+      if (!g || !g->is_group) throw std::runtime_error("model_weights/" + sname + " missing");
+      const jsonmin::Value* sub_cfg = nullptr;
+      if (have_cfg)
+        if (const jsonmin::Value* c = root.get("config"))
+          if (c->kind == jsonmin::Value::Obj)
+            for (auto& kv : c->obj) {
+              const jsonmin::Value& v = kv.second;
+              if (v.kind != jsonmin::Value::Obj) continue;
+              const jsonmin::Value* cc = v.get("config");
+              if (cc && cc->kind == jsonmin::Value::Obj && cc->get("layers") && cc->get("name") && cc->at("name").str == sname) sub_cfg = cc;
+            }
+      if (sub_cfg) parse_submodel(m, *sub_cfg, file.get(), g, true);
+      else {
+        jsonmin::Value ref = jsonmin::parse(reference_submodel_config(sname, g));
+        parse_submodel(m, ref, file.get(), g, true);
+      }
+    }
+  } catch (const FileError&) {
+    throw;
+  } catch (const std::exception& e) {
+    throw FileError{SRCFD_EIO, "cannot load model '" + path + "': " + e.what()};
   }
 }
 

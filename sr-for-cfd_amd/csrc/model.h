@@ -49,6 +49,9 @@ struct FileError {
 };
 void append_h5_submodel(ModelDesc& m, const std::string& path);
 void save_h5_submodel(const ModelDesc& m, int sub_index, const std::string& path);
+// Whole-model file of SuperResolutionAE (`superres_model.save(...)`, sr-ae-conv.ipynb:c586): both sub-models in one file.
+void append_h5_whole(ModelDesc& m, const std::string& path);
+void save_h5_whole(const ModelDesc& m, const std::string& path);
 
 const char* act_name(int act);  // Keras 3 serialised names ("silu", "linear", ...)
 int act_from_name(const std::string& s);

@@ -75,6 +75,14 @@ class SRModel:
         return cls(h, dev)
 
     @classmethod
+    def load_superres_h5(cls, superres_h5, device=None) -> "SRModel":
+        """The whole-model file `superres_model.save(...)` writes (sr-ae-conv.ipynb:c586): encoder + decoder in one .h5."""
+        dev = cls._pick_device(device)
+        h = C.c_void_p()
+        L.check(L.lib.srcfd_model_load_superres_h5(L.enc(superres_h5), dev, C.byref(h)))
+        return cls(h, dev)
+
+    @classmethod
     def from_layers(cls, specs: Sequence[dict], in_shape: Tuple[int, int, int], device=None) -> "SRModel":
         dev = cls._pick_device(device)
         arr = (L.Layer * len(specs))()
@@ -187,6 +195,10 @@ class SRModel:
     def save_h5(self, encoder_h5=None, decoder_h5=None):
         L.check(L.lib.srcfd_model_save_h5(self._h, L.enc(encoder_h5) if encoder_h5 else None,
                                           L.enc(decoder_h5) if decoder_h5 else None))
+
+    def save_superres_h5(self, superres_h5):
+        """`superres_model.save(...)` (sr-ae-conv.ipynb:c586): both sub-models in one legacy Keras-H5 file."""
+        L.check(L.lib.srcfd_model_save_superres_h5(self._h, L.enc(superres_h5)))
 
     # -- forward ------------------------------------------------------------
     def predict(self, x: np.ndarray, in_affine=None, out_affine=None, nan_guard: bool = False,

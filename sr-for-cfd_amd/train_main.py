@@ -107,6 +107,8 @@ def main(argv=None):
         e = os.path.join(args.out_dir, f"vanilla_encoder{args.lr_dim}_to_{args.hr_dim}_{args.suffix}.h5")
         d = os.path.join(args.out_dir, f"vanilla_decoder{args.hr_dim}_from_{args.lr_dim}_{args.suffix}.h5")
         model.save_h5(e, d)
+        # and the whole model in one file, like `superres_model.save(...)` (sr-ae-conv.ipynb:c586)
+        model.save_superres_h5(os.path.join(args.out_dir, f"superres_{args.lr_dim}to{args.hr_dim}_vanilla_ae_{args.suffix}.h5"))
         ds.save_component_stats(os.path.join(args.out_dir, f"standardization_stats_{args.lr_dim}to{args.hr_dim}_{args.suffix}.txt"),
                                 args.lr_dim, args.hr_dim, data["stats_lr"], data["stats_hr"])
         print(json.dumps(report))

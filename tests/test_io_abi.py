@@ -184,6 +184,62 @@ def test_keras_h5_save_load_round_trip(srcfd, oracle, enc_weights, dec_weights, 
         assert out[0] == "Functional" and out[1] == "9"
 
 
+def test_whole_model_superres_file_round_trip(srcfd, enc_weights, dec_weights, tmp_path):
+    """`superres_model.save("superres_10to400_vanilla_ae_*.h5")` (sr-ae-conv.ipynb:c586): encoder + decoder in one legacy
+    Keras-H5 file, groups model_weights/<sub-model>/<layer>/{kernel,bias} (the layout is unpinned: the reference's files are
+    absent).  Round trip through the nested sub-model configs, and through the fallback that assumes the reference
+    architecture when a file has weights only."""
+    m = srcfd.SRModel.from_weights(enc_weights, dec_weights, device=-1)
+    p = str(tmp_path / "superres_10to400_vanilla_ae_test.h5")
+    m.save_superres_h5(p)
+    m2 = srcfd.SRModel.load_superres_h5(p, device=-1)
+    assert m2.has_fused_path and m2.input_shape == (10, 10, 1) and m2.output_shape == (400, 400, 1)
+    assert m2.macs_per_sample == m.macs_per_sample == 140_024_128
+    w1, w2 = m.weights(), m2.weights()
+    assert list(w1) == list(w2) and len(w1) == 22
+    for k in w1:
+        np.testing.assert_array_equal(w1[k], w2[k])
+    assert [(d["name"], d["stride"], d["same"], d["activation"]) for d in m2.layers()] == \
+           [(d["name"], d["stride"], d["same"], d["activation"]) for d in m.layers()]
+    with srcfd.H5File(p) as f:
+        assert f.attr_str("/model_weights", "layer_names") == ["encoder_10", "decoder_400"]
+        assert f.attr_str("/model_weights/encoder_10", "weight_names")[:2] == ["conv2d/kernel", "conv2d/bias"]
+        assert f.shape_dtype("/model_weights/decoder_400/conv2d_transpose/kernel")[0] == (3, 3, 128, 256)
+        assert "SuperResolutionAE" in f.attr_str("/", "model_config")[0]
+    # a weights-only variant (no sub-model configs in model_config): the reader falls back to the reference architecture
+    w = srcfd.H5Writer()
+    w.attr("/", "keras_version", "3.8.0")
+    w.attr("/", "backend", "tensorflow")
+    w.attr("/", "model_config", '{"class_name": "SuperResolutionAE"}')
+    w.group("model_weights")
+    w.attr("/model_weights", "layer_names", ["encoder_10", "decoder_400"])
+    for sub, ws in (("encoder_10", enc_weights), ("decoder_400", dec_weights)):
+        w.group(f"model_weights/{sub}")
+        w.attr(f"/model_weights/{sub}", "weight_names", list(ws))
+        for k, v in ws.items():
+            w.dataset(f"model_weights/{sub}/{k}", v)
+    q = str(tmp_path / "superres_weights_only.h5")
+    w.save(q)
+    m3 = srcfd.SRModel.load_superres_h5(q, device=-1)
+    assert m3.has_fused_path and [(d["name"], d["stride"], d["same"], d["activation"], d["reshape"]) for d in m3.layers()] == \
+                                  [(d["name"], d["stride"], d["same"], d["activation"], d["reshape"]) for d in m.layers()]
+    for k in w1:
+        np.testing.assert_array_equal(m3.weights()[k], w1[k])
+    # the sub-model pair written from it is what the solvers load (PyCFD_ML_accelerated.py:831-832)
+    m3.save_h5(str(tmp_path / "e.h5"), str(tmp_path / "d.h5"))
+    assert srcfd.SRModel.load_h5(str(tmp_path / "e.h5"), str(tmp_path / "d.h5"), device=-1).macs_per_sample == 140_024_128
+    # errors: a sub-model file is not a whole-model file; missing file
+    with pytest.raises(OSError):
+        srcfd.SRModel.load_superres_h5(ENCODER_H5, device=-1)
+    with pytest.raises(FileNotFoundError):
+        srcfd.SRModel.load_superres_h5(str(tmp_path / "nope.h5"), device=-1)
+    if os.path.exists(CONDA_PY):   # h5py reads it
+        code = ("import h5py,json,sys;f=h5py.File(sys.argv[1],'r');c=json.loads(f.attrs['model_config']);"
+                "print(c['class_name'], sorted(c['config'])[0], f['model_weights/decoder_400/dense_1/kernel'].shape)")
+        out = subprocess.check_output([CONDA_PY, "-c", code, p], text=True).split()
+        assert out[0] == "SuperResolutionAE" and out[1] == "decoder_hr"
+
+
 # ---------------------------------------------------------------- stats ------
 def test_stats_parser_matches_reference_rules(srcfd, oracle, tmp_path):
     lr, hr = srcfd.load_stats(STATS_TXT, 10, 400)

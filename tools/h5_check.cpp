@@ -74,6 +74,11 @@ int main(int argc, char** argv) {
       m.infer_shapes();
       ++ok;
     } catch (const srcfd::FileError&) { ++bad; } catch (const std::exception&) { ++bad; }
+    try {   // and as a whole-model (superres_*.h5) file
+      srcfd::ModelDesc w;
+      srcfd::append_h5_whole(w, argv[i]);
+      w.infer_shapes();
+    } catch (const srcfd::FileError&) {} catch (const std::exception&) {}
   }
   std::printf("%d %d %ld\n", ok, bad, reads);
   return 0;
