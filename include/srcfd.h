@@ -208,6 +208,19 @@ int srcfd_resample_device(srcfd_resampler* r, const float* in_dev, int n, double
 int srcfd_predict_resampled(srcfd_model* m, srcfd_resampler* r, const float* x, int n, const float* in_affine,
                             const float* out_affine, double* y, int flags, int64_t* n_nonfinite);
 
+/* ---- input preparation on the device (batched BFS calls) ------------------------------------------
+ * Replaces, per sample (one component of one coarse field), what `ml_super_resolution` does before `predict` in the BFS
+ * solver: `reshape_rectangular_to_square` (bfs_ml_accelerated.py:59-101; X = Ry F Rx^T with the 1-D spline matrices
+ * Ry [lr][h], Rx [lr][w], float64, DEVICE; both NULL = no resampling), `.astype(np.float32)` (:1086), and the adaptive
+ * blend of the training statistics with np.mean / np.std of the float32 field (:1091-1097; adaptive = 0: the training
+ * statistics as they are).  fields_dev float64 (n,h,w); train_stats_dev float64 (n,2) = (mean, std) of each sample's
+ * component; writes x_dev float32 (n,lr,lr) [or (n,h,w)] and in_affine_dev float32 (n,2), the arguments
+ * srcfd_predict_device takes.  The statistics reproduce numpy's float32 arithmetic (pairwise sums, NumPy-2 scalar
+ * promotion) bit for bit.  Sides up to 32. */
+int srcfd_prepare_inputs_device(const double* fields_dev, int n, int h, int w, const double* Ry_dev, const double* Rx_dev, int lr,
+                                const double* train_stats_dev, int adaptive, double blend, float* x_dev, float* in_affine_dev,
+                                void* hip_stream);
+
 /* ---- hand-off into the solver state ---------------------------------------------------------
  * Replaces the three transposed assignments `solver.Var[k, 1:-1, 1:-1] = ml_initial_fields[c].T` and the
  * ghost-cell pass `_apply_bc_wrapper(k)` that follow the SR call (PyCFD_ML_accelerated.py:936-943,

@@ -112,6 +112,7 @@ _protos = {
     "srcfd_trainer_forward_backward": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_float, _p, _p, _p]),
     "srcfd_model_save_superres_h5": (C.c_int, [_p, C.c_char_p]),
     "srcfd_model_load_superres_h5": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_p)]),
+    "srcfd_prepare_inputs_device": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, _p, _p, C.c_int, _p, C.c_int, C.c_double, _p, _p, _p]),
     "srcfd_coarse_solve": (C.c_int, [C.POINTER(CoarseProblem), _p, C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "srcfd_adam_step": (C.c_int, [_p, _p, _p, _p, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float, _p]),
     "srcfd_stats_load": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_double)]),

@@ -221,6 +221,92 @@ __global__ void __launch_bounds__(256) solver_state_f64(const T* __restrict__ fi
 using srcfd::Resampler;
 using srcfd::set_error;
 
+namespace srcfd {
+// ---------------------------------------------------------------------------
+// Input preparation of the BFS call on the device: for every sample (one component of one
+// coarse field, float64 (h, w)):  [optional] aspect-ratio resampling  X = Ry * F * Rx^T  (bfs_ml_accelerated.py:59-101),
+// the float32 cast, and the adaptive-normalisation blend of bfs_ml_accelerated.py:1091-1097
+//     input_mean = np.mean(X32), input_std = np.std(X32)
+//     mean = (1 - b) * mean_train + b * input_mean;   std = (1 - b) * std_train + b * max(input_std, 1e-8)
+// One workgroup per sample.  The statistics follow numpy's arithmetic step by step -- float32 pairwise sums with its
+// eight-accumulator block for n <= 128, float32 division and sqrt, and NumPy-2 scalar promotion of the blend (a Python
+// float next to a float32 scalar is rounded to float32 first) -- so that the (mean, std) pair equals the host recipe's.
+// ---------------------------------------------------------------------------
+__device__ float np_pairwise_sum_f32(const float* a, int n) {   // numpy/_core/src/umath/loops_utils.h.src, pairwise_sum, n <= 128
+  if (n < 8) {
+    float res = 0.f;
+    for (int i = 0; i < n; ++i) res = __fadd_rn(res, a[i]);
+    return res;
+  }
+  float r[8];
+  for (int j = 0; j < 8; ++j) r[j] = a[j];
+  int i = 8;
+  for (; i < n - (n % 8); i += 8)
+    for (int j = 0; j < 8; ++j) r[j] = __fadd_rn(r[j], a[i + j]);
+  float res = __fadd_rn(__fadd_rn(__fadd_rn(r[0], r[1]), __fadd_rn(r[2], r[3])), __fadd_rn(__fadd_rn(r[4], r[5]), __fadd_rn(r[6], r[7])));
+  for (; i < n; ++i) res = __fadd_rn(res, a[i]);
+  return res;
+}
+
+constexpr int PREP_MAX = 32;   // source and target sides up to 32 (the path's coarse fields are 10 x 10)
+
+__global__ void __launch_bounds__(128) prepare_inputs_f64(const double* __restrict__ fields, int h, int w, const double* __restrict__ Ry,
+                                                           const double* __restrict__ Rx, int lr, const double* __restrict__ train_stats,
+                                                           int adaptive, double blend, float* __restrict__ x_out, float* __restrict__ aff_out) {
+  __shared__ double F[PREP_MAX * PREP_MAX], T[PREP_MAX * PREP_MAX];
+  __shared__ float X[PREP_MAX * PREP_MAX], D[PREP_MAX * PREP_MAX];
+  const int s = blockIdx.x, tid = threadIdx.x;
+  const double* src = fields + (size_t)s * h * w;
+  for (int i = tid; i < h * w; i += 128) F[i] = src[i];
+  __syncthreads();
+  const int oh = Ry ? lr : h, ow = Rx ? lr : w;
+  if (Ry) {                       // T = Ry * F   (oh x w), k ascending
+    for (int e = tid; e < oh * w; e += 128) {
+      const int r = e / w, c = e - r * w;
+      double acc = 0.0;
+      for (int k = 0; k < h; ++k) acc = __fma_rn(Ry[r * h + k], F[k * w + c], acc);
+      T[e] = acc;
+    }
+  } else {
+    for (int e = tid; e < h * w; e += 128) T[e] = F[e];
+  }
+  __syncthreads();
+  for (int e = tid; e < oh * ow; e += 128) {   // X = T * Rx^T  (oh x ow)
+    const int r = e / ow, c = e - r * ow;
+    double acc;
+    if (Rx) {
+      acc = 0.0;
+      for (int k = 0; k < w; ++k) acc = __fma_rn(T[r * w + k], Rx[c * w + k], acc);
+    } else acc = T[r * w + c];
+    const float v = (float)acc;
+    X[e] = v;
+    x_out[(size_t)s * oh * ow + e] = v;
+  }
+  __syncthreads();
+  const int n = oh * ow;
+  __shared__ float s_mean;
+  if (tid == 0) s_mean = __fdiv_rn(np_pairwise_sum_f32(X, n), (float)n);
+  __syncthreads();
+  for (int e = tid; e < n; e += 128) { const float d = __fsub_rn(X[e], s_mean); D[e] = __fmul_rn(d, d); }
+  __syncthreads();
+  if (tid == 0) {
+    const double mean_tr = train_stats[2 * s], std_tr = train_stats[2 * s + 1];
+    float mean_o, std_o;
+    if (adaptive) {
+      const float in_mean = s_mean;
+      const float in_std = sqrtf(__fdiv_rn(np_pairwise_sum_f32(D, n), (float)n));   // correctly rounded (hipcc's default for sqrt and divide); __fsqrt_rn is the native approximation
+      // (1 - b) * mean_tr: Python floats (float64); b * np.float32: float32; their sum: the float64 term rounded to float32 first
+      mean_o = __fadd_rn((float)((1.0 - blend) * mean_tr), __fmul_rn((float)blend, in_mean));
+      if (in_std >= (float)1e-8) std_o = __fadd_rn((float)((1.0 - blend) * std_tr), __fmul_rn((float)blend, in_std));
+      else std_o = (float)((1.0 - blend) * std_tr + blend * 1e-8);   // max() picked the Python float: float64 throughout
+    } else {
+      mean_o = (float)mean_tr; std_o = (float)std_tr;
+    }
+    aff_out[2 * s] = mean_o; aff_out[2 * s + 1] = std_o;
+  }
+}
+}  // namespace srcfd
+
 extern "C" {
 
 int srcfd_resampler_create(int device, const double* Ry, const double* Rx, int in_h, int in_w, int out_h, int out_w, srcfd_resampler** out) {
@@ -332,6 +418,22 @@ int srcfd_predict_into_solver_state(srcfd_model* m, srcfd_resampler* r, const fl
     HIPCHECK(hipStreamSynchronize(nullptr));
     return rc;
   });
+}
+
+int srcfd_prepare_inputs_device(const double* fields_dev, int n, int h, int w, const double* Ry_dev, const double* Rx_dev, int lr,
+                                const double* train_stats_dev, int adaptive, double blend, float* x_dev, float* in_affine_dev,
+                                void* hip_stream) {
+  if (n < 0 || (n > 0 && (!fields_dev || !train_stats_dev || !x_dev || !in_affine_dev)) || h < 1 || w < 1 || h > srcfd::PREP_MAX ||
+      w > srcfd::PREP_MAX || ((Ry_dev || Rx_dev) && (lr < 1 || lr > srcfd::PREP_MAX)) || (!Ry_dev) != (!Rx_dev)) {
+    srcfd::set_error("srcfd_prepare_inputs_device: bad arguments (sides up to 32; Ry and Rx together or not at all)");
+    return SRCFD_EINVAL;
+  }
+  if (n == 0) return SRCFD_OK;
+  hipLaunchKernelGGL(srcfd::prepare_inputs_f64, dim3(n), dim3(128), 0, reinterpret_cast<hipStream_t>(hip_stream), fields_dev, h, w, Ry_dev,
+                     Rx_dev, lr, train_stats_dev, adaptive, blend, x_dev, in_affine_dev);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { srcfd::set_error(std::string("prepare_inputs launch failed: ") + hipGetErrorString(e)); return SRCFD_EHIP; }
+  return SRCFD_OK;
 }
 
 }  // extern "C"

@@ -187,6 +187,61 @@ def ml_super_resolution_into_solver(coarse_fields, lr_dim: int, hr_dim: int, sta
     return Var
 
 
+def ml_super_resolution_batch(coarse_batch, lr_dim: int, hr_dim: int, stats_file: str, encoder_file: str, decoder_file: str,
+                              use_aspect_ratio_correction: bool = False, lx: float = 1.0, ly: float = 1.0,
+                              use_adaptive_normalization: bool = False, blend_factor: float = 0.3,
+                              precision: Optional[str] = None, return_device: bool = False):
+    """`ml_super_resolution` for a LIST of coarse fields in one device pass (the batched form of the BFS / LDC call; the
+    reference makes one call per field).  Everything between the float64 coarse fields and the result runs on the GPU:
+    the 10x10 aspect-ratio resampling and the adaptive blend of the statistics (`srcfd_prepare_inputs_device`,
+    bfs_ml_accelerated.py:59-101, 1086-1097), the network with its fused standardise / de-standardise / NaN guard, and the
+    resampling back to the rectangle (bfs_ml_accelerated.py:104-145).  Returns a list of {'u','v','p'} dicts like the
+    per-field call (float32 (hr,hr); float64 after the BFS back-resampling), or with return_device=True the
+    (N, 3, hr, hr) CUDA tensor."""
+    import ctypes as C
+    import torch
+    from . import _lib as L
+    from . import resample as rs
+    n_f = len(coarse_batch)
+    stats_lr, stats_hr = load_stats(stats_file, lr_dim, hr_dim)
+    for f in (encoder_file, decoder_file):
+        if not os.path.exists(f):
+            raise FileNotFoundError(f"model file '{f}' not found")
+    model = kc._device_handle((os.fspath(encoder_file), os.fspath(decoder_file)), precision or kc._DEFAULT_PRECISION)
+    dev = torch.device("cuda", model.device)
+    st = torch.cuda.current_stream(dev)
+    h, w = np.asarray(coarse_batch[0]["u"]).shape
+    fields = np.stack([np.stack([np.asarray(cf[c], np.float64) for c in COMPONENTS]) for cf in coarse_batch]).reshape(3 * n_f, h, w)
+    f_dev = torch.from_numpy(np.ascontiguousarray(fields)).to(dev)
+    train = torch.from_numpy(np.tile(np.array([stats_lr[c] for c in COMPONENTS], np.float64), (n_f, 1))).to(dev)
+    aout = torch.from_numpy(np.tile(np.array([stats_hr[c] for c in COMPONENTS], np.float32), (n_f, 1))).to(dev)
+    resample = use_aspect_ratio_correction and lx != ly
+    Ry = Rx = None
+    if resample:
+        ry, rx = rs.rect_to_square_matrices(w, h, float(lx), float(ly))
+        Ry, Rx = torch.from_numpy(np.array(ry)).to(dev), torch.from_numpy(np.array(rx)).to(dev)
+    side = lr_dim if resample else h
+    x = torch.empty((3 * n_f, side, side, 1), dtype=torch.float32, device=dev)
+    ain = torch.empty((3 * n_f, 2), dtype=torch.float32, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    L.check(L.lib.srcfd_prepare_inputs_device(p(f_dev), 3 * n_f, h, w, p(Ry), p(Rx), lr_dim, p(train), int(bool(use_adaptive_normalization)),
+                                              float(blend_factor), p(x), p(ain), C.c_void_p(st.cuda_stream)))
+    y = torch.empty((3 * n_f, hr_dim, hr_dim, 1), dtype=torch.float32, device=dev)
+    bad = torch.zeros(1, dtype=torch.int64, device=dev)
+    model.predict_device(x, y, in_affine=ain, out_affine=aout, nan_guard=True, nonfinite=bad)
+    if resample:
+        back = rs.square_to_rect_resampler(hr_dim, hr_dim, hr_dim, float(lx), float(ly), model.device)
+        out = back.apply_device(y.view(3 * n_f, hr_dim, hr_dim))
+    else:
+        out = y.view(3 * n_f, hr_dim, hr_dim)
+    _warn_nonfinite(int(bad.item()))
+    out = out.view(n_f, 3, out.shape[-2], out.shape[-1])
+    if return_device:
+        return out
+    host = out.cpu().numpy()
+    return [{c: host[i, k] for k, c in enumerate(COMPONENTS)} for i in range(n_f)]
+
+
 def ml_super_resolution_bfs(coarse_fields, lr_dim, hr_dim, stats_file, encoder_file, decoder_file,
                             use_aspect_ratio_correction: bool = False, lx: float = 1.0, ly: float = 1.0,
                             use_adaptive_normalization: bool = True, blend_factor: float = 0.3, **kw):

@@ -215,6 +215,66 @@ def test_harness_bfs_with_resampling_and_blend_matches_reference_recipe(srcfd, o
 
 
 @pytest.mark.gpu
+def test_batched_call_prepares_its_inputs_on_the_device(srcfd, decoder_h5, coarse_cases):
+    """SURVEY 8f-2 / 8a row a3 on the device: the 10x10 aspect-ratio resampling, the float32 cast and the adaptive blend
+    (np.mean / np.std of the float32 field, NumPy scalar promotion included) for a batch of coarse fields equal the host
+    recipe's numbers -- the (mean, std) pairs bit for bit, the resampled inputs to one float32 ulp -- and the batched call
+    returns what the per-field calls return."""
+    import ctypes as C
+    import torch
+    require_gpu(srcfd)
+    pl = importlib.import_module("sr-for-cfd_amd.pipeline")
+    rs = importlib.import_module("sr-for-cfd_amd.resample")
+    L = importlib.import_module("sr-for-cfd_amd._lib")
+    rng = np.random.default_rng(77)
+    base = coarse_cases["bfs_Re400"]
+    batch = [base] + [{c: base[c] * (1 + 0.05 * rng.standard_normal()) + 0.01 * rng.standard_normal((10, 10)) for c in "uvp"} for _ in range(6)]
+    batch.append({c: np.full((10, 10), 0.25) for c in "uvp"})          # zero variance: the max(input_std, 1e-8) branch
+    lr_stats, _ = srcfd.load_stats(STATS_TXT, 10, 400)
+    dev = torch.device("cuda", 0)
+    fields = np.stack([np.stack([b[c] for c in "uvp"]) for b in batch]).reshape(-1, 10, 10)
+    n = fields.shape[0]
+    ry, rx = rs.rect_to_square_matrices(10, 10, 10.0, 3.0)
+    for resample in (True, False):
+        for adaptive in (1, 0):
+            x = torch.empty((n, 10, 10), dtype=torch.float32, device=dev)
+            ain = torch.empty((n, 2), dtype=torch.float32, device=dev)
+            f_dev = torch.from_numpy(fields).to(dev)
+            tr = torch.from_numpy(np.tile(np.array([lr_stats[c] for c in "uvp"], np.float64), (len(batch), 1))).to(dev)
+            Ry = torch.from_numpy(np.array(ry)).to(dev) if resample else None
+            Rx = torch.from_numpy(np.array(rx)).to(dev) if resample else None
+            p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+            L.check(L.lib.srcfd_prepare_inputs_device(p(f_dev), n, 10, 10, p(Ry), p(Rx), 10, p(tr), adaptive, 0.3, p(x), p(ain), None))
+            torch.cuda.synchronize()
+            xg, ag = x.cpu().numpy(), ain.cpu().numpy()
+            for i, b in enumerate(batch):      # the host recipe: pipeline._prepare's expressions (= bfs_ml_accelerated.py:1086-1097)
+                sq = {c: (ry @ b[c] @ rx.T if resample else b[c]) for c in "uvp"}
+                for k, c in enumerate("uvp"):
+                    x32 = sq[c].astype(np.float32)
+                    np.testing.assert_array_max_ulp(xg[3 * i + k], x32, maxulp=1)
+                    mean_lr, std_lr = lr_stats[c]
+                    if adaptive:
+                        g32 = xg[3 * i + k]    # statistics of the device's own float32 field (it may differ from numpy's by 1 ulp)
+                        input_mean, input_std = g32.reshape(1, -1).mean(axis=1)[0], g32.reshape(1, -1).std(axis=1)[0]
+                        mean_lr = (1 - 0.3) * mean_lr + 0.3 * input_mean
+                        std_lr = (1 - 0.3) * std_lr + 0.3 * max(input_std, 1e-8)
+                    want = np.array([mean_lr, std_lr], np.float32)
+                    np.testing.assert_array_equal(ag[3 * i + k].view(np.uint32), want.view(np.uint32))
+    # the batched call == the per-field calls (BFS defaults: adaptive blend, aspect-ratio correction both ways)
+    kw = dict(use_aspect_ratio_correction=True, lx=10.0, ly=3.0, blend_factor=0.3)
+    got = pl.ml_super_resolution_batch(batch[:4], 10, 400, STATS_TXT, ENCODER_H5, decoder_h5, use_adaptive_normalization=True, **kw)
+    for b, g in zip(batch[:4], got):
+        one = pl.ml_super_resolution_bfs(b, 10, 400, STATS_TXT, ENCODER_H5, decoder_h5, **kw)
+        for c in "uvp":
+            assert g[c].shape == (400, 400) and g[c].dtype == np.float64
+            assert np.linalg.norm(g[c] - one[c]) / np.linalg.norm(one[c]) <= 1e-5
+    ldc = pl.ml_super_resolution_batch([coarse_cases["ldc_Re800_double"], coarse_cases["ldc_Re1000_single"]], 10, 400, STATS_TXT, ENCODER_H5, decoder_h5)
+    one = pl.ml_super_resolution(coarse_cases["ldc_Re1000_single"], 10, 400, STATS_TXT, ENCODER_H5, decoder_h5)
+    for c in "uvp":
+        np.testing.assert_array_equal(ldc[1][c], one[c])
+
+
+@pytest.mark.gpu
 def test_verbose_call_prints_the_reference_style_report_and_same_fields(srcfd, decoder_h5, coarse_cases, capsys):
     """verbose=True reports the blended statistics and the range of every component (the reference prints them on every
     call, bfs_ml_accelerated.py:1096-1145); the quiet default skips those range scans but returns the same arrays."""
