@@ -294,17 +294,18 @@ __global__ void __launch_bounds__(256) splitk_finish16(const float* __restrict__
 //          over 2x8-pixel tiles read from the ring, + de-standardise + guard
 // ---------------------------------------------------------------------------
 // LDS layouts are bank-swizzled for the two access patterns that hit them:
-//  ring (400-level, 16 B per pixel): a row is 8 planes (x & 7) of 50 granules
-//    (x >> 3).  BC writes a wave of pixels 4 apart in x (-> consecutive
+//  ring (400-level, 16 B per pixel): a row is 8 planes (x & 7) of 52 granules
+//    (1 + (x >> 3); granules 0 and 51 stay zero: the SAME padding of the output conv
+//    at the left / right image edge, read like any other pixel -- no per-lane edge tests).  BC writes a wave of pixels 4 apart in x (-> consecutive
 //    granules of two planes, 2-way at worst); D reads 16 tiles 8 apart in x
 //    (-> 16 consecutive granules, conflict-free; the row pitch is a multiple of
 //    256 B so the two window rows of one ds_read_b128 lane group interleave).
 //  L100 (100-level, 4 chunks of 8 channels): [chunk][row][x parity][x >> 1];
 //    A writes pixels 2 apart (-> consecutive), BC reads consecutive pixels
 //    (parity planes 56 granules = 8 mod 16 apart -> conflict-free).
-constexpr int T_RING_ROWS = 18, T_PLANE = 50, T_ROWP = 8 * T_PLANE * 16;
+constexpr int T_RING_ROWS = 18, T_PLANE = 52, T_ROWP = 8 * T_PLANE * 16;   // 50 granules + a zero granule at either end of a plane
 constexpr int T_OFF_RING = 0;
-constexpr int T_OFF_L100 = T_RING_ROWS * T_ROWP;            // 115200
+constexpr int T_OFF_L100 = T_RING_ROWS * T_ROWP;            // 119808
 constexpr int T_L100_BUF = 4 * 212 * 16;                    // 13568
 constexpr int T_OFF_CONST = T_OFF_L100 + 2 * T_L100_BUF;    // blob copied from TailParams::consts
 constexpr int T_OFF_CTR = T_OFF_CONST + TAIL_CONST_BYTES;
@@ -312,7 +313,7 @@ constexpr int T_OFF_ZERO = T_OFF_CTR + 16;                  // 16 zero bytes: wh
 constexpr int T_LDS_BYTES = T_OFF_ZERO + 16;
 static_assert(T_LDS_BYTES <= 160 * 1024, "tail kernel LDS budget");
 
-__device__ __forceinline__ int ring_off(int Y, int X) { return (Y % T_RING_ROWS) * T_ROWP + (((X & 7) * T_PLANE + (X >> 3)) << 4); }
+__device__ __forceinline__ int ring_off(int Y, int X) { return (Y % T_RING_ROWS) * T_ROWP + (((X & 7) * T_PLANE + (X >> 3) + 1) << 4); }
 __device__ __forceinline__ int l100_off(int a, int x, int chunk) { return (chunk * 212 + a * 106 + (x & 1) * 56 + (x >> 1)) << 4; }
 
 // block-wide barrier that leaves global loads / stores in flight: only LDS traffic
@@ -343,6 +344,7 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
   for (int i = tid; i < TAIL_CONST_BYTES / 16; i += 1024)
     reinterpret_cast<uint4*>(smem + T_OFF_CONST)[i] = reinterpret_cast<const uint4*>(p.consts)[i];
   if (tid < 4) reinterpret_cast<int*>(smem + T_OFF_ZERO)[tid] = 0;
+  for (int i = tid; i < T_OFF_L100 / 16; i += 1024) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);   // ring incl. its zero granules
   __syncthreads();
 
   const uint4* wc_f = reinterpret_cast<const uint4*>(cst + TC_OFF_WC);
@@ -357,6 +359,14 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
 #pragma unroll
   for (int cp = 0; cp < 5; ++cp)
     d_xo[cp] = 16 * (d_dx ? (cp < 4 ? 2 * cp * T_PLANE : 1) : (cp == 0 ? 7 * T_PLANE - 1 : (2 * cp - 1) * T_PLANE));
+
+  // D fast path (every row pair that is not at a sample / segment seam): everything that depends on the lane only is
+  // computed here, once; a round adds wave-uniform terms.  (These address and epilogue instructions were 65 of a D item's
+  // vector instructions -- on this chip vector and matrix instructions of a SIMD do not overlap, so they are kernel time.)
+  constexpr int OUTSZ = OUT == 0 ? 4 : 2;
+  const int d_rowlane = d_dy * T_ROWP;                               // window row of this lane's k-group, relative to the item's first
+  const int d_olane = (((lane >> 3) & 1) * 400 + 8 * (lane >> 4) + (lane & 7)) * OUTSZ;   // output byte offset inside the item's row pair
+  const int d_kg = lane >> 4;
 
   // ---- static schedule (per round: 14 BC, 8 A, 16 D items over 16 waves) ----
   // The kernel is VALU-issue bound and wave w runs on SIMD w % 4, so the schedule balances VALU instructions
@@ -377,6 +387,24 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
     if (sq < 2) { d_first = 4 + 2 * sq + (sl - 2); d_cnt = 1; }      // waves 2,3,6,7 -> 4..7
     else { d_first = 8 + 4 * (sq - 2) + 2 * (sl - 2); d_cnt = 2; }   // waves 10,11,14,15 -> 8..15
   }
+
+  int d_b0[2], d_b1[2];   // per D item of this wave: within-row byte offsets of window column pair 0 (pair 4 = + 16) and 1 (pairs 2, 3 = + 2, 4 planes)
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int tx = 16 * ((d_first + i) & 3) + d_tsel;
+    tx = tx < 50 ? tx : 49;
+    d_b0[i] = (tx + 1) * 16 + (d_dx ? 0 : (7 * T_PLANE - 1) * 16);
+    d_b1[i] = (tx + 1) * 16 + (d_dx ? 2 : 1) * T_PLANE * 16;
+  }
+  unsigned bad_wave = 0;  // non-finite outputs zeroed by the fast path (wave-uniform count)
+  // BC item of this wave (bc_item = 2 * pixel tile + ConvT#3 row tile): the lane's 100-level pixel never changes
+  int bc_idx = 32 * (bc_item >= 0 ? bc_item >> 1 : 0) + l31;
+  const bool bc_valid = bc_idx < 200;
+  bc_idx = bc_valid ? bc_idx : 199;
+  const bool bc_a = bc_idx >= 100;
+  const int bc_x = bc_idx - (bc_a ? 100 : 0);
+  const int bc_l0 = l100_off(bc_a ? 1 : 0, bc_x, h);                                              // chunk h; chunk 2 + h is 2 * 212 granules further
+  char* const bc_wbase = ring + ((((bc_x & 1) * (4 * T_PLANE) + (bc_x >> 1) + 1) << 4) + 8 * h);  // x = 4 bc_x + c: plane c + 4 (bc_x & 1), granule (bc_x >> 1) + 1
 
   const int a_px = 32 * a_ct + l31;
   const bool a_valid = a_px < 50;
@@ -431,37 +459,33 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
       const int g = r - 1;
       if (!(bc_item >= 0 && g >= 0 && g < G && !TAIL_ABL(8))) return;
       { int sm, sx, sg, sl; strip_of(g, sm, sx, sg, sl); if (sx < 0) return; }  // warm-up strip of a top segment: nothing above the image
-      const int t = bc_item >> 1, m3 = bc_item & 1;
-      int idx = 32 * t + l31;
-      const bool valid = idx < 200;
-      if (!valid) idx = 199;
-      const int a = idx >= 100 ? 1 : 0, x100 = idx - 100 * a;
+      const int m3 = bc_item & 1;
       const char* src = l100 + (g & 1) * T_L100_BUF;
-      uint4 b0 = *reinterpret_cast<const uint4*>(src + l100_off(a, x100, h)), b1 = *reinterpret_cast<const uint4*>(src + l100_off(a, x100, 2 + h));
+      uint4 b0 = *reinterpret_cast<const uint4*>(src + bc_l0), b1 = *reinterpret_cast<const uint4*>(src + bc_l0 + 2 * 212 * 16);
       f32x16 acc3 = load_bias16(cst + TC_OFF_B3 + h * 64);
       acc3 = mfma32<F16>(w3_f[(m3 * 2 + 0) * 64 + lane], b0, acc3);
       acc3 = mfma32<F16>(w3_f[(m3 * 2 + 1) * 64 + lane], b1, acc3);
       uint32_t f3[8];
       swish_pack16<F16>(acc3, f3, ab_sw);
-      // ring address = row slot (uniform base + small per-lane offset) + swizzled granule of x = 4*x100 + c
-      const int rbase = (8 * g) % T_RING_ROWS;  // tall-image row 8g
-      const int rowv = rbase + 4 * a;
-      char* wbase = ring + (((x100 & 1) * (4 * T_PLANE) + (x100 >> 1)) << 4) + 8 * h;
+      // the item writes ring rows 8g + 4a + 2 m3 + {0, 1} (a = 100-level row of the lane's pixel; the ConvT#3 tap row is m3
+      // for both taps tt): two wave-uniform row offsets per value of a, picked per lane, + the lane's constant granule
+      const int rbase = (8 * g) % T_RING_ROWS;
+      int ra0 = rbase + 2 * m3, ra1 = ra0 + 1, rb0 = ra0 + 4, rb1 = ra0 + 5;
+      ra0 = ra0 >= T_RING_ROWS ? ra0 - T_RING_ROWS : ra0; ra1 = ra1 >= T_RING_ROWS ? ra1 - T_RING_ROWS : ra1;
+      rb0 = rb0 >= T_RING_ROWS ? rb0 - T_RING_ROWS : rb0; rb1 = rb1 >= T_RING_ROWS ? rb1 - T_RING_ROWS : rb1;
+      char* w0 = bc_wbase + (bc_a ? rb0 : ra0) * T_ROWP;
+      char* w1 = bc_wbase + (bc_a ? rb1 : ra1) * T_ROWP;
 #pragma unroll
       for (int tt = 0; tt < 2; ++tt) {
-        const int tap3 = 2 * m3 + tt, a3 = tap3 >> 1, b3 = tap3 & 1;
         uint4 bf = make_uint4(f3[4 * tt], f3[4 * tt + 1], f3[4 * tt + 2], f3[4 * tt + 3]);
         const f32x16 bias4 = load_bias16(cst + TC_OFF_B4 + h * 64);  // re-read per tap: 16 registers less across the swish
         f32x16 acc4 = mfma32<F16>(w4, bf, bias4);
         uint32_t f4[8];
         swish_pack16<F16>(acc4, f4, ab_sw);
-        if (valid) {
+        if (bc_valid) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            int rr = rowv + 2 * a3 + (q >> 1);
-            rr = rr >= T_RING_ROWS ? rr - T_RING_ROWS : rr;
-            *reinterpret_cast<uint2*>(wbase + rr * T_ROWP + (2 * b3 + (q & 1)) * (T_PLANE * 16)) = make_uint2(f4[2 * q], f4[2 * q + 1]);
-          }
+          for (int q = 0; q < 4; ++q)   // register pair q: row q >> 1 of the tap's 2x2 block, plane 2 tt + (q & 1)
+            *reinterpret_cast<uint2*>(((q >> 1) ? w1 : w0) + (2 * tt + (q & 1)) * (T_PLANE * 16)) = make_uint2(f4[2 * q], f4[2 * q + 1]);
         }
       }
     };
@@ -491,7 +515,52 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
     const bool d_warm = gd == G || (S > 1 && sd == 0);   // no regular output rows: flush round, or a segment's warm-up strip
     const bool d_top = !d_warm && s_d == 0;              // first strip of a real sample: row pair 0 = (nothing | row 0)
     {
-      auto do_d = [&](const int item) {  // called (not looped) so no conservative vmcnt(0) lands in front of it
+      // fast path: row pair rp of strip gd, all four window rows inside one sample
+      auto d_fast = [&](const int it, const int rowoff0, const int rowoff1) {
+        const int item = d_first + it, rp = item >> 2, j4 = item & 3;
+        f32x4 acc = {conv_bias, conv_bias, conv_bias, conv_bias};
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+          const int rb = half ? rowoff1 : rowoff0;
+          const char* p0 = smem + rb + d_b0[it];
+          const char* p1 = smem + rb + d_b1[it];
+          uint4 av[5], wv[5];
+          av[0] = *reinterpret_cast<const uint4*>(p0);
+          av[4] = *reinterpret_cast<const uint4*>(p0 + 16);
+          av[1] = *reinterpret_cast<const uint4*>(p1);
+          av[2] = *reinterpret_cast<const uint4*>(p1 + 2 * T_PLANE * 16);
+          av[3] = *reinterpret_cast<const uint4*>(p1 + 4 * T_PLANE * 16);
+#pragma unroll
+          for (int cp = 0; cp < 5; ++cp) wv[cp] = wc_f[(half * 5 + cp) * 64 + lane];
+#pragma unroll
+          for (int cp = 0; cp < 5; ++cp) acc = mfma16<F16>(av[cp], wv[cp], acc);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // accumulator register rr of lane group kg holds tile 16*j4 + 4rr + kg, pixel (oy, ox) = lane & 15: the row pair's
+        // base is wave-uniform, the lane adds a constant, rr an immediate
+        char* orow = reinterpret_cast<char*>(p.out) + (((size_t)sample_d * 400 + (8 * s_d - 1 + 2 * rp)) * 400 + 128 * j4) * OUTSZ;
+        float v[4];
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          float t = acc[rr];
+          if (p.aff_out) t = __fadd_rn(__fmul_rn(t, o_std), o_mean);
+          if (p.nan_guard) {
+            const bool bad = !(fabsf(t) <= 3.402823466e38f) && (j4 < 3 || (rr == 0 && d_kg < 2));
+            bad_wave += (unsigned)__popcll(__ballot(bad));
+            t = bad ? 0.f : t;
+          }
+          v[rr] = t;
+        }
+        auto st = [&](const int rr) {
+          char* o = orow + d_olane + 32 * rr * OUTSZ;
+          if (OUT == 0) *reinterpret_cast<float*>(o) = v[rr];
+          else if (OUT == 1) *reinterpret_cast<uint16_t*>(o) = (uint16_t)(pack2<false>(v[rr], 0.f) & 0xffff);
+          else *reinterpret_cast<uint16_t*>(o) = (uint16_t)(pack2<true>(v[rr], 0.f) & 0xffff);
+        };
+        if (j4 < 3) { st(0); st(1); st(2); st(3); }
+        else if (d_kg < 2) st(0);       // tiles 48, 49 of the row pair; the other 14 of this item do not exist
+      };
+      auto do_d = [&](const int item) {  // seam rows (sample / segment boundaries): called (not looped) so no conservative vmcnt(0) lands in front of it
         const int rp = item >> 2, j4 = item & 3;
         // rp == 0 at a boundary: the pair is (row 399 of the sample that just ended | row 0 of the one that starts)
         const bool emit_prev = rp == 0 && sd == 0 && prev_ends;
@@ -505,7 +574,7 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
         int s0 = sa + d_dy, s1 = s0 + 2;
         s0 = s0 >= T_RING_ROWS ? s0 - T_RING_ROWS : s0;
         s1 = s1 >= T_RING_ROWS ? s1 - T_RING_ROWS : s1;
-        const int r0 = T_OFF_RING + s0 * T_ROWP + tx * 16, r1 = T_OFF_RING + s1 * T_ROWP + tx * 16;
+        const int r0 = T_OFF_RING + s0 * T_ROWP + (tx + 1) * 16, r1 = T_OFF_RING + s1 * T_ROWP + (tx + 1) * 16;
         const bool okf = !(d_dx == 0 && tx == 0), okl = !(d_dx == 1 && tx == 49);
         const int oy = (lane >> 3) & 1, ox = lane & 7;
         const int txo = 16 * j4 + kg;
@@ -560,14 +629,34 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
           }
         }
       };
+      auto run_d = [&]() {
+        if (!d_on || d_cnt < 1) return;
+        const int rp = d_first >> 2;    // both items of a wave sit in the same row pair
+        // wave-uniform: no regular rows at all (flush round / a segment's warm-up strip), or row pair 0 of a strip whose row
+        // above belongs to another sample or lies above the image (first strip of a virtual sample; strip 0 of a real one)
+        const bool seam_round = d_warm || (rp == 0 && (sd == 0 || s_d == 0));
+        if (seam_round) {
+          do_d(d_first);
+          if (d_cnt >= 2) do_d(d_first + 1);
+          return;
+        }
+        // ring byte offsets of window rows (d_dy) and (d_dy + 2) of the row pair: uniform slot + lane row, wrapped at 18 rows
+        // (unsigned min: v - 18 rows wraps around to a huge value unless v is past the end)
+        const int sa = (8 * gd + 16 + 2 * rp) % T_RING_ROWS;
+        unsigned v0 = (unsigned)(sa * T_ROWP + d_rowlane);
+        v0 = min(v0, v0 - (unsigned)(T_RING_ROWS * T_ROWP));
+        unsigned v1 = v0 + 2u * T_ROWP;
+        v1 = min(v1, v1 - (unsigned)(T_RING_ROWS * T_ROWP));
+        d_fast(0, (int)v0, (int)v1);
+        if (d_cnt >= 2) d_fast(1, (int)v0, (int)v1);
+      };
       // stagger: the BC-only-plus-D waves do their latency-bound D items first, so their VALU-heavy
       // BC items overlap the tail (A items) of the waves that started with BC
       if (PROF) ts[0] = __builtin_amdgcn_s_memtime();
       const bool d_first_order = TAIL_ABL(16) ? false : (TAIL_ABL(32) ? true : wave >= 8);
       if (d_first_order) {
         if (!TAIL_ABL(128)) __builtin_amdgcn_s_setprio(3);  // D is a latency chain with few instructions: let it through
-        if (d_on && d_cnt >= 1) do_d(d_first);
-        if (d_on && d_cnt >= 2) do_d(d_first + 1);
+        run_d();
         __builtin_amdgcn_s_setprio(0);
       }
       if (PROF) ts[1] = __builtin_amdgcn_s_memtime();
@@ -575,8 +664,7 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
       if (PROF) ts[2] = __builtin_amdgcn_s_memtime();
       if (!d_first_order) {
         if (!TAIL_ABL(128)) __builtin_amdgcn_s_setprio(3);
-        if (d_on && d_cnt >= 1) do_d(d_first);
-        if (d_on && d_cnt >= 2) do_d(d_first + 1);
+        run_d();
         __builtin_amdgcn_s_setprio(0);
       }
       if (PROF) ts[3] = __builtin_amdgcn_s_memtime();
@@ -625,6 +713,7 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
     o[0] = tD; o[1] = tBC; o[2] = tA; o[3] = tBar; o[4] = __builtin_amdgcn_s_memtime() - tStart;
   }
   if (p.nan_guard && p.nonfinite && bad_count) atomicAdd(p.nonfinite, (unsigned long long)bad_count);
+  if (p.nan_guard && p.nonfinite && bad_wave && lane == 0) atomicAdd(p.nonfinite, (unsigned long long)bad_wave);
 }
 
 // ---------------------------------------------------------------------------

@@ -165,3 +165,19 @@ def test_bench_needs_as_many_devices_as_ranks():
     n = torch.cuda.device_count()
     rc, recs, err = _run_bench(["--gpus", str(n + 1), "--steps", "1", "--warmup", "0", "--no-extras", "--no-cpu-baseline"], {}, timeout=600)
     assert rc != 0 and not recs
+
+
+@pytest.mark.gpu
+def test_rccl_backend_two_gpus():
+    """The real `nccl` (= RCCL) backend: `bench.py --gpus 2` on two GPUs -- sample-sharded inference with the scalar MAX
+    reduction, and the data-parallel training step's flat-gradient all-reduce over xGMI.  Needs two visible devices: on a
+    one-GPU box this is reported as SKIPPED (the N > 1 hardware runs are the driver's)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f"needs 2 GPUs for the RCCL backend, {torch.cuda.device_count()} visible")
+    rc, recs, err = _run_bench(["--gpus", "2", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"], {}, timeout=900)
+    assert rc == 0, err[-2000:]
+    r = recs[0]
+    assert r["n_gpus"] == 2 and r["world_size_reported"] == 2 and r["config"]["backend"] == "nccl"
+    assert r["value"] == pytest.approx(2 * 256 / (r["ms_per_step"] * 1e-3), rel=1e-3) and r["nonfinite"] == 0
+    assert r["train"]["global_batch"] == 16 and "nccl" in r["train"]["collective"] and r["train"]["loss_finite"]

@@ -10,7 +10,7 @@ import csv, glob, collections
 for d in sorted(glob.glob("$OUT/*/")):
     for f in glob.glob(d+"/*/*_counter_collection.csv"):
         agg=collections.defaultdict(lambda: collections.defaultdict(list))
-        for r in csv.DictReader(open(f)): agg[r['Kernel_Name'].split('(')[0][-40:]][r['Counter_Name']].append(float(r['Counter_Value']))
+        for r in csv.DictReader(open(f)): agg[r["Kernel_Name"].split("(")[0][-40:]+" g"+r["Grid_Size"]][r['Counter_Name']].append(float(r['Counter_Value']))
         for k,v in agg.items():
-            if 'tail' in k or 'gemm16' in k or 'mid16' in k: print(k, {c: round(sum(x)/len(x)) for c,x in v.items()})
+            if 'srcfd' in k or 'tail' in k: print(k, {c: round(sum(x)/len(x)) for c,x in v.items()})
 PY
