@@ -539,17 +539,10 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
         // accumulator register rr of lane group kg holds tile 16*j4 + 4rr + kg, pixel (oy, ox) = lane & 15: the row pair's
         // base is wave-uniform, the lane adds a constant, rr an immediate
         char* orow = reinterpret_cast<char*>(p.out) + (((size_t)sample_d * 400 + (8 * s_d - 1 + 2 * rp)) * 400 + 128 * j4) * OUTSZ;
-        float v[4];
+        float v[4] = {acc[0], acc[1], acc[2], acc[3]};
+        if (p.aff_out) {
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) {
-          float t = acc[rr];
-          if (p.aff_out) t = __fadd_rn(__fmul_rn(t, o_std), o_mean);
-          if (p.nan_guard) {
-            const bool bad = !(fabsf(t) <= 3.402823466e38f) && (j4 < 3 || (rr == 0 && d_kg < 2));
-            bad_wave += (unsigned)__popcll(__ballot(bad));
-            t = bad ? 0.f : t;
-          }
-          v[rr] = t;
+          for (int rr = 0; rr < 4; ++rr) v[rr] = __fadd_rn(__fmul_rn(v[rr], o_std), o_mean);
         }
         auto st = [&](const int rr) {
           char* o = orow + d_olane + 32 * rr * OUTSZ;
@@ -557,8 +550,24 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
           else if (OUT == 1) *reinterpret_cast<uint16_t*>(o) = (uint16_t)(pack2<false>(v[rr], 0.f) & 0xffff);
           else *reinterpret_cast<uint16_t*>(o) = (uint16_t)(pack2<true>(v[rr], 0.f) & 0xffff);
         };
-        if (j4 < 3) { st(0); st(1); st(2); st(3); }
-        else if (d_kg < 2) st(0);       // tiles 48, 49 of the row pair; the other 14 of this item do not exist
+        if (j4 < 3) {
+          if (p.nan_guard) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+              const bool bad = !(fabsf(v[rr]) <= 3.402823466e38f);
+              bad_wave += (unsigned)__popcll(__ballot(bad));
+              v[rr] = bad ? 0.f : v[rr];
+            }
+          }
+          st(0); st(1); st(2); st(3);
+        } else if (d_kg < 2) {          // tiles 48, 49 of the row pair; the other 14 of this item do not exist
+          if (p.nan_guard) {
+            const bool bad = !(fabsf(v[0]) <= 3.402823466e38f);
+            bad_wave += (unsigned)__popcll(__ballot(bad));
+            v[0] = bad ? 0.f : v[0];
+          }
+          st(0);
+        }
       };
       auto do_d = [&](const int item) {  // seam rows (sample / segment boundaries): called (not looped) so no conservative vmcnt(0) lands in front of it
         const int rp = item >> 2, j4 = item & 3;
