@@ -308,7 +308,7 @@ class Job:
                 # whole f32 step: all 768 samples' FLOPs over the SUM of every launch of the step (all chunks)
                 fl = 2.0 * MACS_PER_SAMPLE * self.n
                 ach = fl / (tot * 1e-3) / 1e12
-                if tot > ms * 1.02:
+                if tot > ms * 1.10:   # event records between launches add a few per cent
                     raise SystemExit(f"bench.py: kernel times ({tot:.3f} ms) exceed the step ({ms:.3f} ms): profile is not per step")
                 rec["roofline"] = {"bound": "mfma", "kernel": "all f32 kernels of one step (sum over chunks)", "achieved": round(ach, 2),
                                    "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": None,

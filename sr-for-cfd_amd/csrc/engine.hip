@@ -422,9 +422,19 @@ int Model::forward_generic(const float* x_dev, int n, const float* aff_in, const
         ds[q] = ops[i + q].d; ds[q].M = n * ds[q].MH * ds[q].MW;
         Bs[q] = d_pack + ops[i + q].w_off; biases[q] = d_pack + ops[i + q].b_off;
       }
-      rc = launch(desc.layers[op.layer].name.c_str(), s, [&] { return launch_gemm_mfma_group(ds, cnt, X, Bs, biases, Y, s, d_splitk, splitk_floats); });
+      static const bool no_big = [] { const char* e = getenv("SRCFD_NO_GEMM32_BIG"); return e && atoi(e) != 0; }();
+      const bool big = !no_big && gemm32_big_qualifies(ds, cnt);
+      rc = launch(desc.layers[op.layer].name.c_str(), s, [&] {
+        return big ? launch_gemm32_big(ds, cnt, X, Bs, biases, Y, s) : launch_gemm_mfma_group(ds, cnt, X, Bs, biases, Y, s, d_splitk, splitk_floats);
+      });
       if (rc) return rc;
       i = j - 1;
+      continue;
+    }
+    static const bool no_big1 = [] { const char* e = getenv("SRCFD_NO_GEMM32_BIG"); return e && atoi(e) != 0; }();
+    if (!naive && !no_big1 && gemm32_big_qualifies(&d, 1)) {
+      rc = launch(op.name.c_str(), s, [&] { return launch_gemm32_big(&d, 1, X, &B, &bias, Y, s); });
+      if (rc) return rc;
       continue;
     }
     rc = launch(op.name.c_str(), s, [&] { return naive ? launch_gemm_naive(d, X, B, bias, Y, s) : launch_gemm_mfma(d, X, B, bias, Y, s, d_splitk, splitk_floats); });

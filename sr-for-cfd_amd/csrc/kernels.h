@@ -44,6 +44,18 @@ size_t gemm_splitk_ws_floats(const GemmDesc& d, bool batch_invariant = true);
 hipError_t launch_gemm_mfma_group(const GemmDesc* ds, int count, const float* X, const float* const* Bs, const float* const* biases, float* Y,
                                   hipStream_t s, float* ws, size_t ws_floats, bool batch_invariant = true, EpiAux aux = EpiAux());
 size_t gemm_group_ws_floats(const GemmDesc* ds, int count, bool batch_invariant = true);
+// Large launches of the wide decoder layers (ConvT#0's phases as one launch, ConvT#1): kernels_gemm32.hip.  Same arithmetic
+// as launch_gemm_mfma / launch_gemm_mfma_group (bit-identical results), K splits summed inside the workgroup.
+struct Gemm32Group {
+  GemmDesc d[4];
+  const float* B[4];
+  const float* bias[4];
+  int kchunk[4];
+  int count;
+};
+bool gemm32_big_qualifies(const GemmDesc* ds, int count);
+hipError_t launch_gemm32_big(const GemmDesc* ds, int count, const float* X, const float* const* Bs, const float* const* biases, float* Y,
+                             hipStream_t s);
 // Two consecutive kernel == stride == 2 transposed convolutions (CI 32 -> 16 -> 8 channels: ConvT#3 -> ConvT#4 of
 // decoder_400) as one kernel: every input pixel expands to its own 4 x 4 output block, no halo, so the 16-channel
 // intermediate (0.65 GB written + read per 256 samples, these two layers are HBM-bound) never leaves the registers.

@@ -409,6 +409,8 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
   const int a_px = 32 * a_ct + l31;
   const bool a_valid = a_px < 50;
   const int a_pxc = a_valid ? a_px : 49;
+  const unsigned a_lane = (unsigned)(a_pxc * 64 + 8 * h);                       // element offset of this lane's 16-byte pieces inside a 50-level row
+  const int a_dst = l100_off(a_mt >> 1, 2 * (a_valid ? a_px : 0) + (a_mt & 1), 0) + 8 * h;   // L100 granule of chunk 0; chunk q is q * 212 granules further
   uint4 wa[4], xb[4];
 #pragma unroll
   for (int kk = 0; kk < 4; ++kk) { wa[kk] = make_uint4(0, 0, 0, 0); xb[kk] = make_uint4(0, 0, 0, 0); }
@@ -443,7 +445,7 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
     int smp0, s0, sg0, sl0;
     strip_of(0, smp0, s0, sg0, sl0);
     if (s0 >= 0) {
-      const uint16_t* src = p.in + (((size_t)smp0 * 50 + s0) * 50 + a_pxc) * 64 + 8 * h;
+      const uint16_t* src = p.in + ((size_t)smp0 * 50 + s0) * 3200 + a_lane;   // wave-uniform row + the lane's constant offset
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) xb[kk] = *reinterpret_cast<const uint4*>(src + 16 * kk);
     }
@@ -687,7 +689,7 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
       if (r + 1 < G) strip_of(r + 1, n_smp, n_s, n_sg, n_sl);
       if (a_s < 0) {        // warm-up strip above the image: nothing to compute, only fetch the next strip's input
         if (n_s >= 0) {
-          const uint16_t* src = p.in + (((size_t)n_smp * 50 + n_s) * 50 + a_pxc) * 64 + 8 * h;
+          const uint16_t* src = p.in + ((size_t)n_smp * 50 + n_s) * 3200 + a_lane;
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk) xb[kk] = *reinterpret_cast<const uint4*>(src + 16 * kk);
         }
@@ -696,17 +698,16 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
 #pragma unroll
       for (int kk = 0; kk < 4; ++kk) acc = mfma32<F16>(wa[kk], xb[kk], acc);
       if (n_s >= 0) {
-        const uint16_t* src = p.in + (((size_t)n_smp * 50 + n_s) * 50 + a_pxc) * 64 + 8 * h;
+        const uint16_t* src = p.in + ((size_t)n_smp * 50 + n_s) * 3200 + a_lane;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) xb[kk] = *reinterpret_cast<const uint4*>(src + 16 * kk);
       }
       uint32_t f2[8];
       swish_pack16<F16>(acc, f2, ab_sw);
       if (a_valid) {
-        const int a = a_mt >> 1, x100 = 2 * a_px + (a_mt & 1);
-        char* dst = l100 + (r & 1) * T_L100_BUF + 8 * h;
+        char* dst = l100 + (r & 1) * T_L100_BUF + a_dst;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(dst + l100_off(a, x100, q)) = make_uint2(f2[2 * q], f2[2 * q + 1]);
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(dst + q * (212 * 16)) = make_uint2(f2[2 * q], f2[2 * q + 1]);
       }
       }
     }

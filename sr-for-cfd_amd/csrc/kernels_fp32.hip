@@ -36,12 +36,15 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   }
 }
 
-// The parity path's swish: hardware exp2 and reciprocal (<= 2 ulp each) with one Newton step on the reciprocal.  libm
-// expf + IEEE division cost ~35 instructions per activation and were the largest single item of the f32 path's time;
-// this form is ~8 and moves the result by a few 1e-7 relative, an order of magnitude below the f32 accumulation-order
-// differences against the float64 oracle (tests: 1e-5 bar).
+// The parity path's swish: x * rcp(1 + exp2(-log2(e) x)) on the hardware exp2 and reciprocal (<= 1-2 ulp each): 5 vector
+// instructions per activation.  It moves the result by a few 1e-7 relative against libm expf + IEEE division (which cost
+// ~35 instructions and were the largest single item of this path's time), an order of magnitude below the f32
+// accumulation-order differences against the float64 oracle (tests: 1e-5 bar; measured 6e-7 on the full model).  A Newton
+// step on the reciprocal (3 more instructions; the training kernels keep it, act_device.h) bought nothing measurable here,
+// and on this chip vector instructions are not hidden behind the f32 MFMAs (tools/microbench8.hip: their times add).
+// For x -> -inf: exp2 = inf, rcp = 0, x * 0 = -0 (no NaN); x -> +inf: exp2 = 0, x * 1.
 __device__ __forceinline__ float act_apply_precise(float v, int act) {
-  if (act == SRCFD_ACT_SWISH) return v * sigmoid_fast(v);  // act_device.h (overflow-safe Newton step)
+  if (act == SRCFD_ACT_SWISH) return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.4426950408889634f));
   return act_apply(v, act);
 }
 
