@@ -55,6 +55,7 @@ struct Model {
 
   float* buf[2] = {nullptr, nullptr};
   int ws_chunk = 0;
+  size_t ws_per_sample = 0;   // elements per sample the two buffers were sized for (depends on the precision)
   float* d_splitk = nullptr;  // split-K slabs of the skinny f32 GEMMs
   double* d_solver_state = nullptr;  // (3, nx+2, ny+2) + row profiles of the solver hand-off
   size_t solver_state_elems = 0;

@@ -273,7 +273,7 @@ void Model::free_workspace() {
   for (void* p : {(void*)d_x_stage, (void*)d_y_stage, (void*)d_aff, (void*)d_nonfinite, (void*)d_splitk, (void*)d_solver_state}) if (p) (void)hipFree(p);
   d_solver_state = nullptr; solver_state_elems = 0; d_splitk = nullptr; splitk_floats = 0;
   d_x_stage = d_y_stage = nullptr; d_aff = nullptr; d_nonfinite = nullptr;
-  ws_chunk = 0; stage_chunk = 0;
+  ws_chunk = 0; stage_chunk = 0; ws_per_sample = 0;
 }
 
 int Model::init_device() {
@@ -292,33 +292,51 @@ int Model::init_device() {
   return SRCFD_OK;
 }
 
+static bool tail32_disabled() {
+  static const bool off = [] { const char* e = getenv("SRCFD_NO_TAIL32"); return e && atoi(e) != 0; }();
+  return off;
+}
+
+// Largest activation that sits in a ping-pong buffer.  With the streaming tail (tail32) the layers from its first one on
+// never materialise: the largest tensor of the f32 path is then ConvT#1's output (640 KB per sample, not 5.12 MB).
 size_t Model::max_act_elems() const {
   size_t m = (size_t)desc.in_shape[0] * desc.in_shape[1] * desc.in_shape[2];
-  for (auto& L : desc.layers) m = std::max(m, (size_t)L.out_shape[0] * L.out_shape[1] * L.out_shape[2]);
+  const bool streaming = tail32_op >= 0 && !tail32_disabled() && precision != SRCFD_PREC_FP32_NAIVE;   // the bring-up path runs layer by layer
+  const int stop = streaming ? ops[tail32_op].layer : (int)desc.layers.size();
+  for (int i = 0; i < stop; ++i) {
+    const Layer& L = desc.layers[i];
+    m = std::max(m, (size_t)L.out_shape[0] * L.out_shape[1] * L.out_shape[2]);
+  }
   return m;
 }
 
+// Samples per pass of the layer-by-layer path: two buffers of the largest activation within 3 GB, at most 1024 samples
+// (batch 256 = 768 samples runs as one pass with the streaming tail, as three without it).
 int Model::chunk_cap() const {
   size_t per = 2 * max_act_elems() * sizeof(float);
   size_t cap = ((size_t)3 << 30) / std::max<size_t>(per, 1);
-  return (int)std::max<size_t>(1, std::min<size_t>(cap, 256));
+  return (int)std::max<size_t>(1, std::min<size_t>(cap, 1024));
 }
 
 int Model::ensure_workspace(int n) {
   int chunk = std::min(n, chunk_cap());
-  if (chunk <= ws_chunk) return SRCFD_OK;
+  const size_t per = max_act_elems();   // depends on the precision: the bring-up path materialises every layer
+  if (chunk <= ws_chunk && per <= ws_per_sample) return SRCFD_OK;
   drop_graph();  // a captured forward holds the old buffers' addresses
   for (int i = 0; i < 2; ++i) if (buf[i]) { HIPCHECK(hipFree(buf[i])); buf[i] = nullptr; }
   ws_chunk = 0;
-  size_t bytes = (size_t)chunk * max_act_elems() * sizeof(float);
+  size_t bytes = (size_t)chunk * per * sizeof(float);
   for (int i = 0; i < 2; ++i) HIPCHECK(hipMalloc(&buf[i], bytes));
+  ws_per_sample = per;
   size_t need = 0;
   for (size_t i = 0; i < ops.size();) {  // the ops of one layer (ConvT output phases) are launched together: their slabs coexist
     size_t j = i;
     GemmDesc ds[4];
     int cnt = 0;
     for (; j < ops.size() && ops[j].layer == ops[i].layer && cnt < 4; ++j) { ds[cnt] = ops[j].d; ds[cnt].M = chunk * ds[cnt].MH * ds[cnt].MW; ++cnt; }
-    need = std::max(need, gemm_group_ws_floats(ds, cnt));
+    static const bool no_big = [] { const char* e = getenv("SRCFD_NO_GEMM32_BIG"); return e && atoi(e) != 0; }();
+    if (no_big || !gemm32_big_qualifies(ds, cnt))   // gemm32_big sums its K slabs in registers: no slab workspace for those launches
+      need = std::max(need, gemm_group_ws_floats(ds, cnt));
     i = j;
   }
   if (d_splitk) { HIPCHECK(hipFree(d_splitk)); d_splitk = nullptr; }
@@ -373,8 +391,7 @@ int Model::forward_generic(const float* x_dev, int n, const float* aff_in, const
         return launch_gemm_finalize(d, X, B, bias, y_dev, out_dtype, aff_out, flags & SRCFD_FLAG_NAN_GUARD, nonfinite, s);
       });
     }
-    static const bool no_tail32 = [] { const char* e = getenv("SRCFD_NO_TAIL32"); return e && atoi(e) != 0; }();
-    if (!naive && !no_tail32 && (int)i == tail32_op) {  // ConvT#2 -> #3 -> #4 -> output conv + finalize: one streaming kernel
+    if (!naive && !tail32_disabled() && (int)i == tail32_op) {  // ConvT#2 -> #3 -> #4 -> output conv + finalize: one streaming kernel
       Tail32Params tp;
       tp.in = X; tp.out = y_dev; tp.n = n; tp.H = d.MH; tp.W = d.MW;
       tp.w1f = d_pack + t32_w1; tp.b1 = d_pack + t32_b1; tp.w2f = d_pack + t32_w2; tp.b2 = d_pack + t32_b2;

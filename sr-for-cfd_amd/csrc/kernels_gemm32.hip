@@ -37,6 +37,7 @@ template <bool SPLIT>   // SPLIT: some phase sums more than one K slab (needs a 
 __global__ void __launch_bounds__(256) gemm32_big(Gemm32Group g, const float* __restrict__ X, float* __restrict__ Y) {
   __shared__ float As[GB_BM * GB_LDA];
   __shared__ __attribute__((aligned(16))) float Bs[GB_BK * GB_BN];
+  __shared__ int64_t row_out[GB_BM];   // element offset of every tile row's output pixel (-1: past M): the two integer divisions per row are done once per workgroup, not once per accumulator register
   const int ph = blockIdx.z;
   const GemmDesc& d = g.d[ph];
   const int m0 = blockIdx.x * GB_BM, n0 = blockIdx.y * GB_BN;
@@ -61,6 +62,15 @@ __global__ void __launch_bounds__(256) gemm32_big(Gemm32Group g, const float* __
     a_img[j] = (int64_t)img * d.IH * d.IW * d.CI;
     a_y[j] = my * d.ay + d.cy;
     a_x[j] = mx * d.ax + d.cx;
+  }
+  if (tid < GB_BM) {
+    const int m = m0 + tid;
+    int64_t o = -1;
+    if (m < d.M) {
+      const int img = m / per, r = m - img * per, my = r / d.MW, mx = r - my * d.MW;
+      o = (((int64_t)img * d.OH + my * d.os + d.oy0) * d.OW + mx * d.os + d.ox0) * d.OC;
+    }
+    row_out[tid] = o;
   }
   // ---- B tile: thread -> k row tid / 32 (+ 8), columns 4 (tid % 32) ----
   const float* bsrc = B + (int64_t)(tid >> 5) * d.Npad + n0 + 4 * (tid & 31);
@@ -151,10 +161,9 @@ __global__ void __launch_bounds__(256) gemm32_big(Gemm32Group g, const float* __
   const bool sw = d.act == SRCFD_ACT_SWISH;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const int m = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    if (m >= d.M) continue;
-    const int img = m / per, rr = m - img * per, my = rr / d.MW, mx = rr - my * d.MW;
-    float* yrow = Y + (((int64_t)img * d.OH + my * d.os + d.oy0) * d.OW + mx * d.os + d.ox0) * d.OC;
+    const int64_t ro = row_out[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];   // written before the K loop's barriers
+    if (ro < 0) continue;
+    float* yrow = Y + ro;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       if (!col_ok[i]) continue;
