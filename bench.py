@@ -113,16 +113,17 @@ def build_inputs(fields, seed, stats_lr, stats_hr):
     return x, ain, aout
 
 
-def measured_traffic(args):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (bench.py cannot
-    run the profiler on itself); None unless the profile was taken on this exact configuration."""
+def measured_traffic(fields, precision, out_dtype):
+    """HBM bytes per launch of the dominant kernel (16-bit paths) or per step (f32 path) from the committed rocprofv3 PMC
+    passes (bench.py cannot run the profiler on itself); None unless the profile was taken on this exact configuration."""
+    name = "pmc_traffic_fp32.json" if precision == "fp32" else "pmc_traffic_tail.json"
     try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic_tail.json")) as f:
+        with open(os.path.join(ROOT, "profiles", name)) as f:
             t = json.load(f)
     except OSError:
         return None, None
     c = t.get("config", {})
-    if (c.get("fields"), c.get("precision"), c.get("out_dtype")) != (args.fields, args.precision, args.out_dtype):
+    if (c.get("fields"), c.get("precision"), c.get("out_dtype")) != (fields, precision, out_dtype):
         return None, None
     return t["hbm_bytes_per_launch"], t["source"]
 
@@ -291,7 +292,7 @@ class Job:
                 dom = "tail(convT2-4+out)"
                 fl = tail_flops(self.n)
                 ach = fl / (kernels[dom] * 1e-3) / 1e12
-                traffic, traffic_src = measured_traffic(args) if precision == args.precision and out_dtype == args.out_dtype else (None, None)
+                traffic, traffic_src = measured_traffic(args.fields, precision, out_dtype)
                 floor = self.n * 2_240_000 / 64 * 23.6 / 1024 / 2.4e9 * 1e3
                 rec["roofline"] = {
                     "bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
@@ -310,9 +311,14 @@ class Job:
                 ach = fl / (tot * 1e-3) / 1e12
                 if tot > ms * 1.10:   # event records between launches add a few per cent
                     raise SystemExit(f"bench.py: kernel times ({tot:.3f} ms) exceed the step ({ms:.3f} ms): profile is not per step")
-                rec["roofline"] = {"bound": "mfma", "kernel": "all f32 kernels of one step (sum over chunks)", "achieved": round(ach, 2),
-                                   "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": None,
-                                   "avg_launch_ms": round(tot, 4), "algorithmic_flops_per_launch": fl}
+                traffic, traffic_src = measured_traffic(args.fields, precision, out_dtype)
+                rec["roofline"] = {"bound": "mfma", "kernel": "all f32 kernels of one step (sum over all launches)", "achieved": round(ach, 2),
+                                   "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_TFLOPS, 4), "traffic": traffic,
+                                   "traffic_unit": "bytes/step (HBM, PMC)", "traffic_source": traffic_src,
+                                   "algorithmic_bytes_per_launch": self.n * (100 + 160000) * 4,
+                                   "avg_launch_ms": round(tot, 4), "algorithmic_flops_per_launch": fl,
+                                   "note": "f32 MFMAs and vector instructions of a SIMD do not overlap on gfx950 (profiles/r02/d_microbench8...): "
+                                           "the swish / output-conv vector work of this path is paid on top of the MFMA time"}
         return rec, y
 
     # -- config 4: training step ---------------------------------------------------------------------------------
