@@ -475,17 +475,30 @@ def main():
         y_gpu[args.precision] = y_head[:8].cpu().numpy()
     del y_head
     parity = train = tiled = host_io = None
+    extra_errors = {}
+
+    def leg(name, fn):
+        """A sub-record must never cost the headline: an exception in one (on every rank alike: same code, same data shapes)
+        is recorded in the line instead of ending the run."""
+        try:
+            return fn()
+        except Exception as e:   # noqa: BLE001
+            extra_errors[name] = f"{type(e).__name__}: {e}"[:300]
+            return None
+
     if extras:
         if args.precision != "fp32":
-            parity, y_par = job.run_sr("fp32", "f32", max(5, min(args.steps, 20)), min(args.warmup, 3))
-            if "fp32" not in y_gpu and job.rank == 0 and job.world == 1 and not args.no_cpu_baseline:
-                y_gpu["fp32"] = y_par[:8].cpu().numpy()
-            del y_par
+            def _parity():
+                rec, y_par = job.run_sr("fp32", "f32", max(5, min(args.steps, 20)), min(args.warmup, 3))
+                if "fp32" not in y_gpu and job.rank == 0 and job.world == 1 and not args.no_cpu_baseline:
+                    y_gpu["fp32"] = y_par[:8].cpu().numpy()
+                return rec
+            parity = leg("parity_path", _parity)
         torch.cuda.empty_cache()
-        train = job.run_train()
-        tiled = job.run_tiled()
+        train = leg("train", job.run_train)
+        tiled = leg("tiled", job.run_tiled)
         if job.rank == 0 and job.world == 1:
-            host_io = job.run_host_io()
+            host_io = leg("host_io", job.run_host_io)
 
     cpu = None
     if job.rank == 0 and job.world == 1 and not args.no_cpu_baseline:
@@ -512,6 +525,8 @@ def main():
             "parity_path": parity, "train": train, "tiled": tiled, "host_io": host_io,
             "env": env,
         }
+        if extra_errors:
+            out["sub_record_errors"] = extra_errors
         if bad_env:
             out["INVALID_diagnostic_run"] = bad_env   # SRCFD_BENCH_ALLOW_DIAG=1 with a DIAG=1 build: tools/ablate*.sh only
         print(json.dumps(out))

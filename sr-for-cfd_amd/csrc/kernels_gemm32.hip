@@ -184,6 +184,9 @@ bool gemm32_big_qualifies(const GemmDesc* ds, int count) {
     const GemmDesc& d = ds[i];
     if (d.M <= 0 || d.K <= 0 || d.CI % 16 != 0 || d.K % 16 != 0 || d.Npad % 128 != 0 || d.Npad != ds[0].Npad) return false;
     if (d.act != SRCFD_ACT_SWISH && d.act != SRCFD_ACT_LINEAR) return false;
+    int kchunk = d.K;
+    (void)gemm_splitk_splits(d, &kchunk, true);
+    if (kchunk % GB_BK != 0) return false;   // a K slab of the batch-invariant split must be whole 16-deep tiles
     tiles += (int64_t)((d.M + GB_BM - 1) / GB_BM) * (d.Npad / GB_BN);
   }
   return tiles >= 1024;

@@ -209,6 +209,17 @@ def ml_super_resolution_batch(coarse_batch, lr_dim: int, hr_dim: int, stats_file
             raise FileNotFoundError(f"model file '{f}' not found")
     model = kc._device_handle((os.fspath(encoder_file), os.fspath(decoder_file)), precision or kc._DEFAULT_PRECISION)
     dev = torch.device("cuda", model.device)
+    with torch.cuda.device(dev):     # the preparation kernel is launched on this device's current stream
+        return _super_resolution_batch_on_device(coarse_batch, n_f, model, dev, stats_lr, stats_hr, lr_dim, hr_dim, use_aspect_ratio_correction,
+                                                 lx, ly, use_adaptive_normalization, blend_factor, return_device)
+
+
+def _super_resolution_batch_on_device(coarse_batch, n_f, model, dev, stats_lr, stats_hr, lr_dim, hr_dim, use_aspect_ratio_correction, lx, ly,
+                                      use_adaptive_normalization, blend_factor, return_device):
+    import ctypes as C
+    import torch
+    from . import _lib as L
+    from . import resample as rs
     st = torch.cuda.current_stream(dev)
     h, w = np.asarray(coarse_batch[0]["u"]).shape
     fields = np.stack([np.stack([np.asarray(cf[c], np.float64) for c in COMPONENTS]) for cf in coarse_batch]).reshape(3 * n_f, h, w)
