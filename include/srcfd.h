@@ -248,6 +248,8 @@ int srcfd_predict_into_solver_state(srcfd_model* m, srcfd_resampler* r, const fl
  * residuals turn NaN / Inf (the reference raises ValueError, :487-492). */
 #define SRCFD_SCHEME_QUICK 0
 #define SRCFD_SCHEME_UPWIND 1
+#define SRCFD_CASE_LDC 0
+#define SRCFD_CASE_BFS 1
 typedef struct srcfd_coarse_problem {
   int nx, ny;
   double lx, ly;
@@ -257,6 +259,12 @@ typedef struct srcfd_coarse_problem {
   double tolerance[3];       /* convergence_criteria u, v, p on rms / dt */
   int bc_type[3][4];
   double bc_value[3][4];
+  /* backward-facing step (bfs_ml_accelerated.py:471-673): SRCFD_CASE_BFS overrides the left boundary with a wall below
+   * step_height and a parabolic inlet (bulk velocity Ub over channel_height) above it, and under-relaxes u, v, p with
+   * relax[] after each solve.  SRCFD_CASE_LDC ignores these five fields. */
+  int case_type;             /* SRCFD_CASE_* */
+  double relax[3];
+  double step_height, channel_height, bulk_velocity;
 } srcfd_coarse_problem;
 int srcfd_coarse_solve(const srcfd_coarse_problem* problem, double* var_out, int* iterations, double rms[3]);
 

@@ -43,7 +43,9 @@ class CoarseProblem(C.Structure):
     _fields_ = [("nx", C.c_int), ("ny", C.c_int), ("lx", C.c_double), ("ly", C.c_double),
                 ("reynolds", C.c_double), ("rho", C.c_double), ("dt", C.c_double),
                 ("scheme", C.c_int), ("max_iterations", C.c_int), ("tolerance", C.c_double * 3),
-                ("bc_type", (C.c_int * 4) * 3), ("bc_value", (C.c_double * 4) * 3)]
+                ("bc_type", (C.c_int * 4) * 3), ("bc_value", (C.c_double * 4) * 3),
+                ("case_type", C.c_int), ("relax", C.c_double * 3),
+                ("step_height", C.c_double), ("channel_height", C.c_double), ("bulk_velocity", C.c_double)]
 
 
 class SolverBC(C.Structure):

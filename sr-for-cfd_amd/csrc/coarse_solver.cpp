@@ -5,7 +5,9 @@
 //   simple_upwind, diffusive_flux, update_flux, solve_momentum_*, solve_pressure, correct_velocity) and
 //   :377-395, 433-505 (CFDSolver._initialize_fields, _implicit_solve, _convergence_check, solve)
 // so that BASELINE config 1's coarse 10x10 input (Re = 400, which the reference checkout does not contain) can be produced
-// here.  A 10x10 problem is a few kB and a few thousand sweeps: this is host code on purpose; the hot path starts after it.
+// here; and, with case_type = SRCFD_CASE_BFS, the backward-facing-step variant of the same loop that produces BASELINE
+// config 3's input (bfs_ml_accelerated.py:233-468 kernels, :523-562 mixed wall / parabolic inlet on the left boundary,
+// :626-673 _implicit_solve with under-relaxation of u, v and p, :675-707 _convergence_check).  A 10x10 problem is a few kB and a few thousand sweeps: this is host code on purpose; the hot path starts after it.
 //
 // Differences from the reference, on purpose: its point sweeps run inside numba `prange` loops that update Var in place
 // (a benign data race: rows are relaxed in whatever order the threads run, the reference's own runs differ by ~2e-7);
@@ -126,13 +128,39 @@ void solve_pressure(Grid& g, double dt, double rho) {  // :299-321
   }
 }
 
+// CFDSolver._apply_bfs_inlet, bfs_ml_accelerated.py:523-562: below the step the left boundary is a no-slip wall, above it a
+// parabolic u profile with v = 0.  Applying it for k = 0 also rewrites v's ghost cells of the open part, as the reference does.
+void apply_bfs_inlet(Grid& g, int k, double step_h, double h, double Ub) {
+  if (k > 1) return;
+  for (int j = 1; j <= g.ny; ++j) {
+    const double y = (j - 0.5) * g.dy;
+    if (y < step_h) { g.v(k, 0, j) = -g.v(k, 1, j); continue; }
+    if (k == 1) { g.v(1, 0, j) = -g.v(1, 1, j); continue; }
+    double yp = y - step_h;
+    if (yp < 0.0) yp = 0.0;
+    if (yp > h) yp = h;
+    const double u_in = 6.0 * Ub * (yp / h) * (1.0 - (yp / h));
+    g.v(0, 0, j) = 2.0 * u_in - g.v(0, 1, j);
+    g.v(1, 0, j) = -g.v(1, 1, j);
+  }
+}
+
+void under_relax(Grid& g, int k, double alpha) {  // bfs_ml_accelerated.py:371-375
+  for (int i = 1; i <= g.nx; ++i)
+    for (int j = 1; j <= g.ny; ++j) {
+      const double o = g.Old[(size_t)k * g.sx + (size_t)i * g.sy + j];
+      g.v(k, i, j) = o + alpha * (g.v(k, i, j) - o);
+    }
+}
+
 }  // namespace
 
 extern "C" int srcfd_coarse_solve(const srcfd_coarse_problem* pb, double* var_out, int* iterations, double rms_out[3]) {
   using srcfd::set_error;
   if (!pb || !var_out) { set_error("srcfd_coarse_solve: bad arguments"); return SRCFD_EINVAL; }
   if (pb->nx < 3 || pb->ny < 3 || pb->nx > 4096 || pb->ny > 4096 || !(pb->lx > 0) || !(pb->ly > 0) || !(pb->reynolds > 0) || !(pb->rho > 0) ||
-      !(pb->dt > 0) || pb->max_iterations < 0 || (pb->scheme != SRCFD_SCHEME_QUICK && pb->scheme != SRCFD_SCHEME_UPWIND)) {
+      !(pb->dt > 0) || pb->max_iterations < 0 || (pb->scheme != SRCFD_SCHEME_QUICK && pb->scheme != SRCFD_SCHEME_UPWIND) ||
+      (pb->case_type != SRCFD_CASE_LDC && pb->case_type != SRCFD_CASE_BFS) || (pb->case_type == SRCFD_CASE_BFS && !(pb->channel_height > 0))) {
     set_error("srcfd_coarse_solve: bad problem description");
     return SRCFD_EINVAL;
   }
@@ -142,8 +170,13 @@ extern "C" int srcfd_coarse_solve(const srcfd_coarse_problem* pb, double* var_ou
   g.Var.assign((size_t)3 * g.sx, 0.0); g.Old.assign((size_t)3 * g.sx, 0.0); g.Ff.assign((size_t)4 * g.sx, 0.0);
   const double nu = 1.0 / pb->reynolds;  // FluidProperties, :79-85
   const bool quick = pb->scheme == SRCFD_SCHEME_QUICK;
+  const bool bfs = pb->case_type == SRCFD_CASE_BFS;
+  auto bc = [&](int k) {   // _apply_bc_wrapper (bfs_ml_accelerated.py:564-569); the cavity solver has no inlet override
+    apply_bc(g, k, pb->bc_type[k], pb->bc_value[k]);
+    if (bfs) apply_bfs_inlet(g, k, pb->step_height, pb->channel_height, pb->bulk_velocity);
+  };
   // _initialize_fields, :377-390
-  for (int k = 0; k < 3; ++k) apply_bc(g, k, pb->bc_type[k], pb->bc_value[k]);
+  for (int k = 0; k < 3; ++k) bc(k);
   g.Old = g.Var;
   linear_interpolation(g);
   int count = 0;
@@ -152,10 +185,16 @@ extern "C" int srcfd_coarse_solve(const srcfd_coarse_problem* pb, double* var_ou
   while (!converged && count < pb->max_iterations) {   // solve, :411-424
     ++count;
     // _implicit_solve, :433-470
-    for (int k = 0; k < 2; ++k) { solve_momentum(g, quick, k, pb->dt, nu); apply_bc(g, k, pb->bc_type[k], pb->bc_value[k]); }
+    // (BFS: each solve is followed by under-relaxation against the previous iterate, bfs_ml_accelerated.py:642-659)
+    for (int k = 0; k < 2; ++k) {
+      solve_momentum(g, quick, k, pb->dt, nu);
+      if (bfs) under_relax(g, k, pb->relax[k]);
+      bc(k);
+    }
     linear_interpolation(g);
     solve_pressure(g, pb->dt, pb->rho);
-    apply_bc(g, 2, pb->bc_type[2], pb->bc_value[2]);
+    if (bfs) under_relax(g, 2, pb->relax[2]);
+    bc(2);
     double res[3] = {0, 0, 0};
     for (int i = 1; i <= g.nx; ++i)       // correct_velocity, :323-335
       for (int j = 1; j <= g.ny; ++j) {
@@ -166,8 +205,8 @@ extern "C" int srcfd_coarse_solve(const srcfd_coarse_problem* pb, double* var_ou
           res[k] += d * d;
         }
       }
-    apply_bc(g, 0, pb->bc_type[0], pb->bc_value[0]);
-    apply_bc(g, 1, pb->bc_type[1], pb->bc_value[1]);
+    bc(0);
+    bc(1);
     for (int i = 1; i <= g.nx; ++i)       // update_flux, :242-249
       for (int j = 1; j <= g.ny; ++j) {
         g.f(0, i, j) += -pb->dt / pb->rho * (g.v(2, i + 1, j) - g.v(2, i, j)) * g.dy / g.dx;

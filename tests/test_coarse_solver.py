@@ -103,3 +103,44 @@ def test_upwind_scheme_boundary_objects_and_errors(coarse):
         coarse.solve_coarse(1000.0, bc=wild, max_iterations=50)
     with pytest.raises(Exception):
         coarse.solve_coarse(100.0, nx=1)
+
+
+def test_backward_facing_step_run_matches_the_reference_field(srcfd, coarse, tmp_path):
+    """BASELINE config 3's input, produced here: the reference's __main__ settings (bfs_ml_accelerated.py:1705-1812: Re 400,
+    lx 10, ly 3, step 1, h 2, Ub 1, dt 2e-3, UPWIND, relaxation 0.5 / 0.5 / 0.2, cap 100 000) against the coarse field the
+    reference itself stored (outputs/<BFS run>/bfs_coarse_Re400_10x10_100000_coarse_iterations.h5 -- as its name says, the
+    run ends at the iteration cap, so there is no stopping-rule ambiguity).  The reference's 14 stored runs differ from each
+    other by up to 1.9e-7 (thread order of the in-place sweeps); ours is inside that spread."""
+    ref = srcfd.read_coarse_fields(os.path.join(GOLDEN, "coarse_bfs_Re400.h5"))
+    got = coarse.run_bfs_coarse_simulation(400.0, 10, bc=coarse.BFS_DEFAULT, relaxation_factors={"u": 0.5, "v": 0.5, "p": 0.2},
+                                           output_dir=str(tmp_path))
+    for c in "uvp":                      # p is pinned by the Dirichlet outlet: no free constant here
+        assert got[c].shape == (10, 10)
+        assert np.abs(got[c] - ref[c]).max() <= 2e-7, (c, np.abs(got[c] - ref[c]).max())
+    # bc=None gives run_coarse_simulation's own default set (:945-951); its u_left value is overridden by the inlet, so: same bits
+    dflt = coarse.run_bfs_coarse_simulation(400.0, 10)
+    for c in "uvp":
+        np.testing.assert_array_equal(dflt[c], got[c])
+    # the inlet: wall below the step (cells with y < 1: j = 1..3 of dy = 0.3 -> y = 0.15, 0.45, 0.75), parabola above it
+    var, it, rms = coarse.solve_coarse(400.0, 10, 10, 10.0, 3.0, 0.002, "UPWIND", bc=coarse.BFS_DEFAULT, max_iterations=200,
+                                       bfs={"step_height": 1.0, "h": 2.0, "Ub": 1.0})
+    assert it == 200
+    y = (np.arange(1, 11) - 0.5) * 0.3
+    u_face = 0.5 * (var[0, 0, 1:-1] + var[0, 1, 1:-1])            # value the ghost cell enforces on the boundary face
+    yp = np.clip(y - 1.0, 0.0, 2.0)
+    np.testing.assert_allclose(u_face, np.where(y < 1.0, 0.0, 6.0 * (yp / 2.0) * (1.0 - yp / 2.0)), atol=1e-15)
+    np.testing.assert_allclose(0.5 * (var[1, 0, 1:-1] + var[1, 1, 1:-1]), 0.0, atol=1e-15)
+    np.testing.assert_array_equal(var[2, -1, 1:-1], -var[2, -2, 1:-1])   # p = 0 on the outlet face
+    # file: the reference's name and layout, with the BFS attributes (bfs_ml_accelerated.py:726-757)
+    p = tmp_path / "bfs_coarse_Re400.0_10x10_100000_coarse_iterations.h5"
+    assert p.exists()
+    back = srcfd.read_coarse_fields(str(p))
+    np.testing.assert_array_equal(back["u"], got["u"])
+    with srcfd.H5File(str(p)) as f:
+        assert f.attr_str("Re400.0_mesh10x10", "case_name") == ["backward facing step"]
+    # under-relaxation really is applied: alpha = 1 for all three is a different (here unstable or at least different) iteration
+    v2, _, _ = coarse.solve_coarse(400.0, 10, 10, 10.0, 3.0, 0.002, "UPWIND", bc=coarse.BFS_DEFAULT, max_iterations=50,
+                                   bfs={"step_height": 1.0, "h": 2.0, "Ub": 1.0}, relaxation_factors={"u": 1.0, "v": 1.0, "p": 1.0})
+    v1, _, _ = coarse.solve_coarse(400.0, 10, 10, 10.0, 3.0, 0.002, "UPWIND", bc=coarse.BFS_DEFAULT, max_iterations=50,
+                                   bfs={"step_height": 1.0, "h": 2.0, "Ub": 1.0})
+    assert np.abs(v1 - v2).max() > 1e-6

@@ -215,6 +215,23 @@ def test_harness_bfs_with_resampling_and_blend_matches_reference_recipe(srcfd, o
 
 
 @pytest.mark.gpu
+def test_config3_end_to_end_from_a_coarse_bfs_solve_made_here(srcfd, decoder_h5, coarse_cases):
+    """BASELINE config 3 without any stored input: coarse backward-facing-step solve (csrc/coarse_solver.cpp, the reference's
+    __main__ settings) -> ml_super_resolution with aspect-ratio correction and blend 0.3.  The coarse field is within the
+    reference's own run-to-run spread of its stored one (tests/test_coarse_solver.py), so the two SR results agree to that."""
+    require_gpu(srcfd)
+    pl = importlib.import_module("sr-for-cfd_amd.pipeline")
+    coarse = importlib.import_module("sr-for-cfd_amd.coarse")
+    solved = coarse.run_bfs_coarse_simulation(400.0, 10, bc=coarse.BFS_DEFAULT)
+    kw = dict(use_aspect_ratio_correction=True, lx=10.0, ly=3.0, blend_factor=0.3)
+    a = pl.ml_super_resolution_bfs(solved, 10, 400, STATS_TXT, ENCODER_H5, decoder_h5, **kw)
+    b = pl.ml_super_resolution_bfs(coarse_cases["bfs_Re400"], 10, 400, STATS_TXT, ENCODER_H5, decoder_h5, **kw)
+    for c in "uvp":
+        assert a[c].shape == (400, 400) and np.isfinite(a[c]).all()
+        assert np.linalg.norm(a[c] - b[c]) / np.linalg.norm(b[c]) <= 1e-5
+
+
+@pytest.mark.gpu
 def test_batched_call_prepares_its_inputs_on_the_device(srcfd, decoder_h5, coarse_cases):
     """SURVEY 8f-2 / 8a row a3 on the device: the 10x10 aspect-ratio resampling, the float32 cast and the adaptive blend
     (np.mean / np.std of the float32 field, NumPy scalar promotion included) for a batch of coarse fields equal the host
