@@ -56,6 +56,9 @@ struct Pack16 {  // one per operand type (bf16, f16)
   void* d_consts = nullptr;
   void* d_w2f = nullptr;
   void* d_w1f = nullptr;   // mid16: ConvT#1 operands
+  void* d_encf = nullptr;  // enc16: conv2d_1, dense, latent_vector operand fragments (one blob)
+  size_t enc_wd_off = 0, enc_wl_off = 0;  // byte offsets of the dense / latent fragments in d_encf
+  float* d_encb = nullptr; // enc16: conv2d_1 bias fragments (128 floats)
   float* d_midb = nullptr; // mid16: bias fragments (b0f 128 floats, then b1f 64 floats)
   bool built = false;
 };
@@ -73,6 +76,7 @@ struct FusedState {
   int cap = 0;
   int t1_buf = 0;  // which act[] holds ConvT#1's output after the last forward
   int num_cus = 256;
+  bool enc_ok = false;     // the encoder has the shape enc16 is written for
 };
 
 static double scale_in(const ModelDesc& md, const std::vector<int>& cl, int i) {
@@ -126,6 +130,16 @@ int fused_init(Model& m) {
     fs->ops.push_back(o);
   }
   if (fs->ops.size() != 9) { set_error("fused path: unexpected plan shape"); return SRCFD_EINVAL; }
+  {  // enc16 is written for encoder_10 exactly: 3x3 s1 pad-1 conv 64->128 on 5x5, dense 3200->128, latent 128->64 (padded)
+    const GemmDesc& c2 = fs->ops[0].d; const GemmDesc& de = fs->ops[1].d; const GemmDesc& la = fs->ops[2].d;
+    const Layer& l0 = md.layers[fs->cl[0]];
+    fs->enc_ok = fs->ops[0].layer == 1 && fs->ops[1].layer == 2 && fs->ops[2].layer == 3 && l0.act == SRCFD_ACT_SWISH &&
+                 l0.kernel.size() == 9 * 64 && c2.act == SRCFD_ACT_SWISH &&
+                 c2.TY == 3 && c2.TX == 3 && c2.CI == 64 && c2.N == 128 && c2.IH == 5 && c2.IW == 5 && c2.MH == 5 && c2.MW == 5 && c2.ay == 1 &&
+                 c2.ax == 1 && c2.by == 1 && c2.bx == 1 && c2.cy == -1 && c2.cx == -1 && fs->ops[0].Kpad == 576 &&
+                 de.MH == 1 && de.MW == 1 && de.K == 3200 && de.N == 128 && fs->ops[1].Kpad == 3200 &&
+                 la.MH == 1 && la.MW == 1 && la.K == 128 && la.N == 64 && fs->ops[2].Kpad == 128;
+  }
   HIPCHECK(hipMalloc(&fs->d_f32, fs->f32.size() * sizeof(float)));
   HIPCHECK(hipMemcpy(fs->d_f32, fs->f32.data(), fs->f32.size() * sizeof(float), hipMemcpyHostToDevice));
   return SRCFD_OK;
@@ -153,6 +167,36 @@ static int build_pack(Model& m, FusedState* fs, bool f16) {
   }
   HIPCHECK(hipMalloc(&P.d_w, w.size() * sizeof(uint16_t)));
   HIPCHECK(hipMemcpy(P.d_w, w.data(), w.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  if (fs->enc_ok) {
+    // ---- enc16 operands: the same 16-bit values, re-ordered so that one lane's MFMA A operand is one 16-byte load ----
+    const uint16_t* W2 = w.data() + fs->ops[0].w_off;   // [128][576]
+    const uint16_t* WD = w.data() + fs->ops[1].w_off;   // [128][3200]
+    const uint16_t* WL = w.data() + fs->ops[2].w_off;   // [64][128]
+    std::vector<uint16_t> ef;
+    ef.reserve((size_t)(4 * 36 + 8 * 100 + 4 * 4) * 512);
+    for (int mt = 0; mt < 4; ++mt)         // 32x32x16: lane l = row l % 32, k = 16 ks + 8 (l / 32) + j
+      for (int ks = 0; ks < 36; ++ks)
+        for (int l = 0; l < 64; ++l)
+          for (int j = 0; j < 8; ++j) ef.push_back(W2[(size_t)(mt * 32 + (l & 31)) * 576 + ks * 16 + (l >> 5) * 8 + j]);
+    P.enc_wd_off = ef.size() * 2;
+    for (int ft = 0; ft < 8; ++ft)         // 16x16x32: lane l = row l % 16, k = 32 ks + 8 (l / 16) + j
+      for (int ks = 0; ks < 100; ++ks)
+        for (int l = 0; l < 64; ++l)
+          for (int j = 0; j < 8; ++j) ef.push_back(WD[(size_t)(ft * 16 + (l & 15)) * 3200 + ks * 32 + (l >> 4) * 8 + j]);
+    P.enc_wl_off = ef.size() * 2;
+    for (int ft = 0; ft < 4; ++ft)
+      for (int ks = 0; ks < 4; ++ks)
+        for (int l = 0; l < 64; ++l)
+          for (int j = 0; j < 8; ++j) ef.push_back(WL[(size_t)(ft * 16 + (l & 15)) * 128 + ks * 32 + (l >> 4) * 8 + j]);
+    HIPCHECK(hipMalloc(&P.d_encf, ef.size() * sizeof(uint16_t)));
+    HIPCHECK(hipMemcpy(P.d_encf, ef.data(), ef.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    std::vector<float> eb(128);
+    for (int mt = 0; mt < 4; ++mt)
+      for (int hh = 0; hh < 2; ++hh)
+        for (int r = 0; r < 16; ++r) eb[(mt * 2 + hh) * 16 + r] = fs->f32[fs->ops[0].b_off + 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * hh];
+    HIPCHECK(hipMalloc(&P.d_encb, eb.size() * sizeof(float)));
+    HIPCHECK(hipMemcpy(P.d_encb, eb.data(), eb.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
 
   // ---- tail constants ----
   const Layer& L2 = md.layers[fs->cl[7]];   // ConvT 64->32, kernel (2,2,32,64)
@@ -257,6 +301,8 @@ void fused_free(Model& m) {
     if (P.d_w2f) (void)hipFree(P.d_w2f);
     if (P.d_w1f) (void)hipFree(P.d_w1f);
     if (P.d_midb) (void)hipFree(P.d_midb);
+    if (P.d_encf) (void)hipFree(P.d_encf);
+    if (P.d_encb) (void)hipFree(P.d_encb);
   }
   if (fs->d_f32) (void)hipFree(fs->d_f32);
   for (auto* b : fs->act) if (b) (void)hipFree(b);
@@ -303,12 +349,46 @@ int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, cons
     const float* ain = aff_in ? aff_in + 2 * (size_t)i0 : nullptr;
     const float* aout = aff_out ? aff_out + 2 * (size_t)i0 : nullptr;
     int cur = 0;
-    rc = m.launch("conv2d", s, [&] { return launch_enc_conv1_16(f16, xin, ain, fs->d_f32 + fs->c1w_off, fs->d_f32 + fs->c1b_off, fs->act[0], c, s); });
-    if (rc) return rc;
-    // functional A/B switch of the tests (both implementations of the network's middle are complete): read per call
+    // functional A/B switches of the tests (both implementations of the encoder and of the network's middle are complete): read per call
+    const bool use_enc = fs->enc_ok && [] { const char* e = getenv("SRCFD_ENC"); return !e || atoi(e) != 0; }();  // 0: layer-by-layer encoder
     const bool use_mid = [] { const char* e = getenv("SRCFD_MID"); return !e || atoi(e) != 0; }();  // 0: generic GEMMs (A/B, tests)
+    if (use_enc) {
+      EncParams ep;
+      ep.x = xin; ep.affine = ain; ep.n = c;
+      ep.w1 = fs->d_f32 + fs->c1w_off; ep.b1 = fs->d_f32 + fs->c1b_off;
+      ep.w2f = P.d_encf; ep.b2f = P.d_encb;
+      ep.wdf = (const char*)P.d_encf + P.enc_wd_off; ep.bd = fs->d_f32 + fs->ops[1].b_off;
+      ep.wlf = (const char*)P.d_encf + P.enc_wl_off; ep.bl = fs->d_f32 + fs->ops[2].b_off;
+      ep.z = fs->act[1];
+      ep.act_dense = fs->ops[1].d.act; ep.act_latent = fs->ops[2].d.act;
+      ep.prof = nullptr;
+#ifdef SRCFD_DIAG
+      static unsigned long long* d_eprof = nullptr;
+      static int eprof_calls = 0;
+      static const bool eprof = getenv("SRCFD_ENC_PROF") != nullptr;
+      if (eprof && !d_eprof) HIPCHECK(hipMalloc(&d_eprof, 64 * sizeof(unsigned long long)));
+      ep.prof = eprof ? d_eprof : nullptr;
+#endif
+      rc = m.launch("encoder(conv2d..latent_vector)", s, [&] { return launch_enc16(f16, ep, s); });
+      if (rc) return rc;
+#ifdef SRCFD_DIAG
+      if (eprof && ++eprof_calls == 20) {
+        unsigned long long hbuf[64];
+        HIPCHECK(hipStreamSynchronize(s));
+        HIPCHECK(hipMemcpy(hbuf, d_eprof, sizeof(hbuf), hipMemcpyDeviceToHost));
+        fprintf(stderr, "enc16 workgroup 7, s_memtime ticks since entry: staged, conv2d, conv2d_1 MFMA, A2 ready, dense, end\n");
+        for (int w = 0; w < 8; ++w)
+          fprintf(stderr, "  wave %d: %6llu %6llu %6llu %6llu %6llu %6llu\n", w, hbuf[w * 8 + 1], hbuf[w * 8 + 2], hbuf[w * 8 + 3], hbuf[w * 8 + 4], hbuf[w * 8 + 5], hbuf[w * 8 + 6]);
+      }
+#endif
+      cur = 1;   // where the layer-by-layer chain leaves the latent vectors, too
+    } else {
+      rc = m.launch("conv2d", s, [&] { return launch_enc_conv1_16(f16, xin, ain, fs->d_f32 + fs->c1w_off, fs->d_f32 + fs->c1b_off, fs->act[0], c, s); });
+      if (rc) return rc;
+    }
     int prev_layer = -1;
     for (const Op16& o : fs->ops) {
+      if (use_enc && o.layer < 4) continue;  // conv2d_1, dense, latent_vector ran inside enc16
       if (use_mid && o.layer >= 5) break;  // ConvT#0 / ConvT#1 run in the fused mid kernel below
       if (o.layer != prev_layer && prev_layer >= 0) cur ^= 1;
       prev_layer = o.layer;

@@ -63,6 +63,26 @@ struct MidParams {
 };
 hipError_t launch_mid16(bool f16, const MidParams& p, int waves /*4, 8 or 16 per workgroup*/, hipStream_t s);
 
+// The whole encoder in one launch (kernels_enc16.hip): conv2d -> conv2d_1 -> dense -> latent_vector
+constexpr int ENC_G = 5;   // samples per workgroup
+struct EncParams {
+  const float* x;          // (n,10,10,1) f32
+  const float* affine;     // (n,2) mean,std or null
+  int n;
+  const float* w1;         // conv2d weights [9][64] f32, scaled
+  const float* b1;         // conv2d bias [64] f32, scaled
+  const void* w2f;         // conv2d_1 A operands [channel tile 4][k-step 36][64 lanes] x 16 B (32x32x16; k = tap*64 + ci)
+  const float* b2f;        // conv2d_1 bias as accumulator init [channel tile 4][lane half 2][16]
+  const void* wdf;         // dense A operands [feature tile 8][k-step 100][64 lanes] x 16 B (16x16x32)
+  const float* bd;         // dense bias [128], scaled
+  const void* wlf;         // latent_vector A operands [feature tile 4][k-step 4][64 lanes] x 16 B
+  const float* bl;         // latent_vector bias [64] (50 + zero padding)
+  uint16_t* z;             // (n,64) latent vectors, 16-bit
+  int act_dense, act_latent;
+  unsigned long long* prof;  // diagnostic (-DSRCFD_DIAG, SRCFD_ENC_PROF): cycle stamps of workgroup 7 [8 waves][8], else null
+};
+hipError_t launch_enc16(bool f16, const EncParams& p, hipStream_t s);
+
 hipError_t launch_enc_conv1_16(bool f16, const float* x, const float* affine, const float* w, const float* b, uint16_t* y, int n, hipStream_t s);
 // part/splits: optional split-K (dense layers with few rows): one f32 slab (M x Npad) per K slice in `part`,
 // summed in slice order by a finish kernel (deterministic)

@@ -18,12 +18,15 @@ from conftest import STATS_TXT, require_gpu
 pytestmark = pytest.mark.gpu
 LOG2E = math.log2(math.e)
 
-# (vs emulation, vs float64 oracle).  Measured on MI355X: f16 1.8e-4 / 8.9e-4, bf16 5.5e-3 / 7.0e-3.
+# (vs emulation, vs float64 oracle).  Measured on MI355X: f16 6.1e-4 / 9.0e-4, bf16 5.5e-3 / 7.5e-3.
 # bf16-vs-emulation is not tighter than bf16-vs-f64 because a last-bit difference in an f32 sum
 # flips bf16 roundings (2^-8 relative each) that then propagate; the f16 row is the logic check.
+# The maximum over samples is set by such flips, not by the typical sample: per sample the f16 path sits at 0.8-1.9e-4
+# from the emulation and a single flipped rounding of one of the 50 latent components moves that sample to ~6e-4
+# (tools/enc_ab.py: the one-launch encoder and the layer-by-layer chain each have one such sample -- a different one).
 TOL = {
     "bf16": (1e-2, 2e-2),
-    "f16": (6e-4, 3e-3),
+    "f16": (1.2e-3, 3e-3),
 }
 
 
@@ -85,6 +88,34 @@ def test_full_model(srcfd, oracle, enc_weights, dec_weights, refs, kind):
     assert y.shape == (6, 400, 400, 1) and np.isfinite(y).all()
     assert e_emu <= TOL[kind][0]
     assert e_f64 <= TOL[kind][1]
+
+
+@pytest.mark.parametrize("kind", ["bf16", "f16"])
+def test_one_launch_encoder_against_the_layer_by_layer_chain(srcfd, oracle, enc_weights, dec_weights, refs, kind, monkeypatch):
+    """enc16 (conv2d -> conv2d_1 -> dense -> latent_vector in one kernel, 5 samples per workgroup) and the four-launch chain
+    it replaces (SRCFD_ENC=0) are two complete implementations of rows a7-a10: both within the 16-bit tolerance of the
+    emulation, close to each other, and enc16's rows do not depend on the batch they sit in (partial last workgroups:
+    n = 1, 6, 7, 11) or, with standardisation fused in, on where the affine is applied."""
+    require_gpu(srcfd)
+    m = srcfd.SRModel.from_weights(enc_weights, dec_weights, device=0)
+    m.precision = kind
+    x = refs["x"]
+    y_enc = m.predict(x)
+    monkeypatch.setenv("SRCFD_ENC", "0")
+    y_chain = m.predict(x)
+    monkeypatch.delenv("SRCFD_ENC")
+    for y in (y_enc, y_chain):
+        assert oracle.rel_l2(y, refs[kind][0]) <= TOL[kind][0]
+        assert oracle.rel_l2(y, refs["f64"]) <= TOL[kind][1]
+    assert oracle.rel_l2(y_enc, y_chain) <= TOL[kind][0]
+    rng = np.random.default_rng(5)
+    xs = rng.standard_normal((11, 10, 10, 1)).astype(np.float32)
+    y11 = m.predict(xs)
+    for lo, hi in ((0, 1), (4, 10), (3, 10), (10, 11)):
+        np.testing.assert_array_equal(m.predict(xs[lo:hi]), y11[lo:hi])
+    ain = np.stack([rng.standard_normal(11) * 0.1, rng.uniform(0.5, 2.0, 11)], 1).astype(np.float32)
+    xn = ((xs - ain[:, 0].reshape(11, 1, 1, 1)) / ain[:, 1].reshape(11, 1, 1, 1)).astype(np.float32)
+    np.testing.assert_array_equal(m.predict(xs, in_affine=ain), m.predict(xn))
 
 
 def test_bf16_batch_larger_than_cu_count_and_affine(srcfd, oracle, enc_weights, dec_weights):
