@@ -55,19 +55,28 @@ __device__ __forceinline__ void swish_pack16(const f32x16& dd, uint32_t (&o)[8],
     for (int i = 0; i < 8; ++i) o[i] = pack2<F16>(dd[2 * i], dd[2 * i + 1]);
     return;
   }
-  float u[16], e[16];
+  // exp2 and rcp per element (quarter rate, 8.5 cycles per wave instruction); the add and the multiply as packed f32
+  // pairs: 5.5 cycles per v_pk_* instruction = 2.7 per element against 4.5 for the plain forms (tools/microbench8.hip)
+  f32x2 u2[8], e2[8];
+  const f32x2 one2 = {1.0f, 1.0f};
 #pragma unroll
-  for (int i = 0; i < 16; ++i) u[i] = dd[i];
+  for (int i = 0; i < 8; ++i) u2[i] = f32x2{dd[2 * i], dd[2 * i + 1]};
 #pragma unroll
-  for (int i = 0; i < 16; ++i) e[i] = __builtin_amdgcn_exp2f(-u[i]);  // builtin: hipcc pads the MFMA -> VALU read hazard itself
+  for (int i = 0; i < 8; ++i) {
+    e2[i].x = __builtin_amdgcn_exp2f(-u2[i].x);  // builtin: hipcc pads the MFMA -> VALU read hazard itself
+    e2[i].y = __builtin_amdgcn_exp2f(-u2[i].y);
+  }
 #pragma unroll
-  for (int i = 0; i < 16; ++i) asm volatile("v_add_f32 %0, 1.0, %0" : "+v"(e[i]));
+  for (int i = 0; i < 8; ++i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(e2[i]) : "v"(one2));
 #pragma unroll
-  for (int i = 0; i < 16; ++i) asm volatile("v_rcp_f32 %0, %0" : "+v"(e[i]));
+  for (int i = 0; i < 8; ++i) {
+    asm volatile("v_rcp_f32 %0, %0" : "+v"(e2[i].x));
+    asm volatile("v_rcp_f32 %0, %0" : "+v"(e2[i].y));
+  }
 #pragma unroll
-  for (int i = 0; i < 16; ++i) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(e[i]) : "v"(u[i]));
+  for (int i = 0; i < 8; ++i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(e2[i]) : "v"(u2[i]));
 #pragma unroll
-  for (int i = 0; i < 8; ++i) o[i] = pack2<F16>(e[2 * i], e[2 * i + 1]);
+  for (int i = 0; i < 8; ++i) o[i] = pack2<F16>(e2[i].x, e2[i].y);
 }
 
 __device__ __forceinline__ f32x16 load_bias16(const char* base) {

@@ -352,6 +352,7 @@ int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, cons
     // functional A/B switches of the tests (both implementations of the encoder and of the network's middle are complete): read per call
     const bool use_enc = fs->enc_ok && [] { const char* e = getenv("SRCFD_ENC"); return !e || atoi(e) != 0; }();  // 0: layer-by-layer encoder
     const bool use_mid = [] { const char* e = getenv("SRCFD_MID"); return !e || atoi(e) != 0; }();  // 0: generic GEMMs (A/B, tests)
+    const bool use_d1 = [] { const char* e = getenv("SRCFD_DENSE1"); return !e || atoi(e) != 0; }();  // 0: dense_1 on the generic GEMM
     if (use_enc) {
       EncParams ep;
       ep.x = xin; ep.affine = ain; ep.n = c;
@@ -400,7 +401,10 @@ int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, cons
       int splits = 1;
       if (d.MH == 1 && d.MW == 1 && d.K >= 1024) splits = std::max(1, std::min(16, d.K / 256));
       if (splits > 1 && (size_t)splits * d.M * d.Npad > fs->part_elems) splits = 1;
-      rc = m.launch(o.name.c_str(), s, [&] { return launch_gemm16(f16, d, X, P.d_w + o.w_off, o.Kpad, fs->d_f32 + o.b_off, Y, fs->d_part, splits, s); });
+      if (use_d1 && o.layer == 4 && dense1_16_qualifies(d, o.Kpad))
+        rc = m.launch(o.name.c_str(), s, [&] { return launch_dense1_16(f16, d, X, P.d_w + o.w_off, fs->d_f32 + o.b_off, Y, s); });
+      else
+        rc = m.launch(o.name.c_str(), s, [&] { return launch_gemm16(f16, d, X, P.d_w + o.w_off, o.Kpad, fs->d_f32 + o.b_off, Y, fs->d_part, splits, s); });
       if (rc) return rc;
     }
     if (use_mid) {

@@ -82,6 +82,9 @@ struct EncParams {
   unsigned long long* prof;  // diagnostic (-DSRCFD_DIAG, SRCFD_ENC_PROF): cycle stamps of workgroup 7 [8 waves][8], else null
 };
 hipError_t launch_enc16(bool f16, const EncParams& p, hipStream_t s);
+// Dense with one 64-deep k tile and N a multiple of 144 (dense_1: 64 -> 36 864): one workgroup per 144 features, all samples
+bool dense1_16_qualifies(const GemmDesc& d, int Kpad);
+hipError_t launch_dense1_16(bool f16, const GemmDesc& d, const uint16_t* X, const uint16_t* Wt, const float* bias, uint16_t* Y, hipStream_t s);
 
 hipError_t launch_enc_conv1_16(bool f16, const float* x, const float* affine, const float* w, const float* b, uint16_t* y, int n, hipStream_t s);
 // part/splits: optional split-K (dense layers with few rows): one f32 slab (M x Npad) per K slice in `part`,

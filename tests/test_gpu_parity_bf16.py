@@ -104,10 +104,14 @@ def test_one_launch_encoder_against_the_layer_by_layer_chain(srcfd, oracle, enc_
     monkeypatch.setenv("SRCFD_ENC", "0")
     y_chain = m.predict(x)
     monkeypatch.delenv("SRCFD_ENC")
-    for y in (y_enc, y_chain):
+    monkeypatch.setenv("SRCFD_DENSE1", "0")        # dense_1 (64 -> 36 864) on the generic implicit GEMM instead of dense1_16
+    y_gemm_d1 = m.predict(x)
+    monkeypatch.delenv("SRCFD_DENSE1")
+    for y in (y_enc, y_chain, y_gemm_d1):
         assert oracle.rel_l2(y, refs[kind][0]) <= TOL[kind][0]
         assert oracle.rel_l2(y, refs["f64"]) <= TOL[kind][1]
     assert oracle.rel_l2(y_enc, y_chain) <= TOL[kind][0]
+    assert oracle.rel_l2(y_enc, y_gemm_d1) <= TOL[kind][0]
     rng = np.random.default_rng(5)
     xs = rng.standard_normal((11, 10, 10, 1)).astype(np.float32)
     y11 = m.predict(xs)
