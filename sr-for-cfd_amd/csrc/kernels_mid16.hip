@@ -38,7 +38,7 @@ template <int NW> struct MidCfg {
   static constexpr int PATCH = (PX / 12 + 3) * 12 + 16;
   static constexpr int OFF_W = (PATCH + 1) * M_PITCH * 2;       // bytes; row PATCH is all zero
   static constexpr int MAIN_END = OFF_W + 128 * M_PITCH * 2;
-  static constexpr int T1_END = 16384 + NW * 32 * 144;          // ConvT#1 stage: two operand tiles + per-wave store tiles
+  static constexpr int T1_END = 32768 + NW * 32 * 144;          // ConvT#1 stage: half of its operands (4 tiles x 8 KB) + per-wave store tiles
   static constexpr int OFF_META = MAIN_END > T1_END ? MAIN_END : T1_END;
   static constexpr int LDS = OFF_META + 3 * PX * 4;
   static constexpr int NTHR = 64 * NW;
@@ -49,7 +49,7 @@ template <int NW> struct MidCfg {
 template <bool F16, int NW>
 __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
   using C = MidCfg<NW>;
-  static_assert(C::OFF_META >= 16384 + NW * 32 * 144, "ConvT#1 operand tiles (2 x 8 KB) + per-wave store tiles are staged over the patch + weight tiles");
+  static_assert(C::OFF_META >= 32768 + NW * 32 * 144, "ConvT#1 operand tiles (4 x 8 KB) + per-wave store tiles are staged over the patch + weight tiles");
   extern __shared__ __attribute__((aligned(16))) char msm[];
   uint16_t* Ps = reinterpret_cast<uint16_t*>(msm);
   uint16_t* Ws = reinterpret_cast<uint16_t*>(msm + C::OFF_W);
@@ -58,10 +58,11 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
   int* row_mx = row_my + C::PX;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
-  const int phase = blockIdx.y, py = phase >> 1, px = phase & 1;
+  const int phase = blockIdx.y, blk = blockIdx.x;
+  const int py = phase >> 1, px = phase & 1;
   const int TY = py ? 1 : 2, TX = px ? 1 : 2, NT = TY * TX;
   const int MH = py ? 12 : 13, MW = px ? 12 : 13, per = MH * MW;
-  const int M = p.n * per, m0 = blockIdx.x * C::PX;
+  const int M = p.n * per, m0 = blk * C::PX;
   if (m0 >= M) return;
   const uint16_t* Wt = p.w0[phase];
   const int Kp = p.kpad[phase];
@@ -111,15 +112,18 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
       pr[j] = r < NP ? *reinterpret_cast<const u32x4*>(p.in + (size_t)(lo + r) * 256 + c * 64 + c8 * 8) : u32x4{0, 0, 0, 0};
     }
   };
-  // ConvT#1 operand tiles (8 KB = 512 chunks of 16 B each, one per (tap, 32-channel half)) are double-buffered in
-  // LDS; the next tile is fetched into registers while the current one feeds the MFMAs
-  constexpr int W1CH = C::NTHR >= 512 ? 1 : 512 / C::NTHR;
-  u32x4 w1r[W1CH];
+  // ConvT#1's 64 KB of A operands (8 tiles of 8 KB = 512 chunks of 16 B, one per (tap, 32-channel half)) go through the LDS
+  // the main loop has left, in two halves of four tiles, by global_load_lds (no registers: the accumulators, the packed
+  // B operands and the swish temporaries fill the file in that stage); the waves work through a half without
+  // synchronising with each other
+  constexpr int W1CH = 2048 / C::NTHR;
+  static_assert(W1CH * C::NTHR == 2048, "a half of ConvT#1's operands divides evenly over the workgroup");
   const u32x4* w1g = reinterpret_cast<const u32x4*>(p.w1f);
-  auto g2r_w1 = [&](int tile) {
+  auto g2l_w1 = [&](int half) {   // lane-linear LDS image: wave w's j-th instruction fills chunks (w*64 + NTHR*j) .. +63
 #pragma unroll
     for (int j = 0; j < W1CH; ++j)
-      if (C::NTHR <= 512 || tid < 512) w1r[j] = w1g[tile * 512 + tid + C::NTHR * j];
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w1g + half * 2048 + tid + C::NTHR * j),
+                                       (__attribute__((address_space(3))) void*)(msm + (size_t)(wave * 64 + C::NTHR * j) * 16), 16, 0, 0);
   };
   auto r2l_w = [&]() {
 #pragma unroll
@@ -167,7 +171,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
   }
 
   // ---- ConvT#0 epilogue: swish, pack; the packed accumulators are ConvT#1's B operands ----
-  g2r_w1(0);  // ConvT#1's first operand tile is in flight during the swish below
+  // ConvT#1's first operand half is in flight during the swish below
+  if (!MID_ABL(2)) g2l_w1(0);
   uint32_t fb[4][8];
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) swish_pack16<F16>(acc[mt], fb[mt]);
@@ -177,24 +182,22 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
   // Each tap's 32 pixels x 64 channels are transposed through a wave-private LDS tile so that the
   // global stores are whole 128-byte pixel rows (16 B per lane, 8 lanes per pixel) instead of
   // 8-byte pieces 512 B apart -- the scattered form was store-issue bound (~0.06 ms per batch).
-  uint4* w1s = reinterpret_cast<uint4*>(msm);          // two 8 KB operand tiles
-  char* stage = msm + 16384 + wave * (32 * 144);       // [32 pixels][144 B]
+  uint4* w1s = reinterpret_cast<uint4*>(msm);          // four 8 KB operand tiles
+  char* stage = msm + 32768 + wave * (32 * 144);       // [32 pixels][144 B]
   const int Y = 2 * my + py, X = 2 * mx + px;  // 25x25-level pixel
   const int obase = img >= 0 ? ((img * 50 + 2 * Y) * 50 + 2 * X) * 64 : -1;  // element offset of tap (0,0)
-  auto r2l_w1 = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < W1CH; ++j)
-      if (C::NTHR <= 512 || tid < 512) reinterpret_cast<u32x4*>(w1s)[buf * 512 + tid + C::NTHR * j] = w1r[j];
-  };
   if (!MID_ABL(2)) {
-    r2l_w1(0);
-    __syncthreads();
+    __syncthreads();   // (drains the global_load_lds above: hipcc puts vmcnt(0) in front of a barrier while one is in flight)
 #pragma unroll 1
     for (int jj = 0; jj < 8; ++jj) {
       const int tap = jj >> 1, jh = jj & 1;
-      if (jj + 1 < 8) g2r_w1(jj + 1);
+      if (jj == 4) {   // second half: the only point of the stage where the waves meet (its load latency is exposed once)
+        __syncthreads();
+        g2l_w1(1);
+        __syncthreads();
+      }
       f32x16 a1 = load_bias16(reinterpret_cast<const char*>(p.b1f) + (jh * 2 + h) * 64);
-      const uint4* wt = w1s + (jj & 1) * 512 + lane;
+      const uint4* wt = w1s + (jj & 3) * 512 + lane;
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
         const uint4 wf = wt[s * 64];
@@ -217,8 +220,6 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
           if (ob >= 0) *reinterpret_cast<uint4*>(p.out + ob + toff + (lane & 7) * 8) = v;
         }
       }
-      if (jj + 1 < 8) r2l_w1((jj + 1) & 1);
-      __syncthreads();
     }
   }
 }
