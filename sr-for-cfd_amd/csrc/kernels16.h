@@ -59,7 +59,7 @@ struct MidParams {
   const float* b0f;        // ConvT#0 bias as accumulator init [m-tile 4][lane half 2][16]
   const void* w1f;         // ConvT#1 A operands [m-tile 8][k-step 8][64 lanes] x 16 B, k in accumulator order
   const float* b1f;        // ConvT#1 bias as accumulator init [channel half 2][lane half 2][16]
-  int ablate;              // diagnostic (SRCFD_MID_ABLATE): 1 no main-loop MFMA, 2 no ConvT#1 stage, 4 no operand loads
+  int ablate;              // diagnostic (SRCFD_MID_ABLATE): 1 no main-loop MFMA, 2 no ConvT#1 stage, 4 no operand loads, 8 no global stores, 16 no ConvT#1 swish
 };
 hipError_t launch_mid16(bool f16, const MidParams& p, int waves /*4, 8 or 16 per workgroup*/, hipStream_t s);
 

@@ -37,7 +37,7 @@ template <int NW> struct MidCfg {
   // plus the row above the first one and one row of slack for the partial first/last rows
   static constexpr int PATCH = (PX / 12 + 3) * 12 + 16;
   static constexpr int OFF_W = (PATCH + 1) * M_PITCH * 2;       // bytes; row PATCH is all zero
-  static constexpr int MAIN_END = OFF_W + 128 * M_PITCH * 2;
+  static constexpr int MAIN_END = OFF_W + 2 * 16384;            // two weight tiles of [128 rows][64 k] at 128 B per row (XOR-swizzled)
   static constexpr int T1_END = 32768 + NW * 32 * 144;          // ConvT#1 stage: half of its operands (4 tiles x 8 KB) + per-wave store tiles
   static constexpr int OFF_META = MAIN_END > T1_END ? MAIN_END : T1_END;
   static constexpr int LDS = OFF_META + 3 * PX * 4;
@@ -100,10 +100,17 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
   // native vector type: arrays of HIP's uint4 struct were left in scratch by the compiler (store/reload around every
   // prefetch), which serialised the global loads
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 wr[C::WCH], pr[C::PCH];
-  auto g2r_w = [&](int t, int c) {
+  u32x4 pr[C::PCH];
+  // Weight tiles go global -> LDS directly (global_load_lds: no registers, no ds_write pass), two buffers.  The LDS image
+  // is lane-linear (chunk index = row * 8 + slot = tid + NTHR * j), so the bank swizzle sits on the SOURCE address: slot
+  // `sl` of row r holds k-chunk sl ^ ((r >> 1) & 7), and the fragment reads below apply the same XOR.
+  auto g2l_w = [&](int t, int c, int buf) {
 #pragma unroll
-    for (int j = 0; j < C::WCH; ++j) wr[j] = *reinterpret_cast<const u32x4*>(Wt + (xrow + RSTEP * j) * Kp + t * 256 + c * 64 + c8 * 8);
+    for (int j = 0; j < C::WCH; ++j) {
+      const int r = xrow + RSTEP * j;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wt + r * Kp + t * 256 + c * 64 + ((c8 ^ ((r >> 1) & 7)) * 8)),
+                                       (__attribute__((address_space(3))) void*)(msm + C::OFF_W + buf * 16384 + (size_t)(wave * 64 + C::NTHR * j) * 16), 16, 0, 0);
+    }
   };
   auto g2r_p = [&](int c) {
 #pragma unroll
@@ -125,10 +132,6 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w1g + half * 2048 + tid + C::NTHR * j),
                                        (__attribute__((address_space(3))) void*)(msm + (size_t)(wave * 64 + C::NTHR * j) * 16), 16, 0, 0);
   };
-  auto r2l_w = [&]() {
-#pragma unroll
-    for (int j = 0; j < C::WCH; ++j) *reinterpret_cast<u32x4*>(Ws + (xrow + RSTEP * j) * M_PITCH + c8 * 8) = wr[j];
-  };
   auto r2l_p = [&]() {
 #pragma unroll
     for (int j = 0; j < C::PCH; ++j) {
@@ -143,32 +146,37 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
   for (int mt = 0; mt < 4; ++mt) acc[mt] = load_bias16(reinterpret_cast<const char*>(p.b0f) + (mt * 2 + h) * 64);
 
   const int NS = 4 * NT;  // stages: 64-channel chunk c = s / NT (outer), tap t = s % NT (inner)
-  g2r_w(0, 0);
-  g2r_p(0);
-  const uint16_t* wsl = Ws + l31 * M_PITCH + h * 8;
+  if (!MID_ABL(4)) { g2r_p(0); g2l_w(0, 0, 0); }
+  // A-fragment reads: row mt*32 + l31, k-chunk 2 kk + h at slot (2 kk + h) ^ ((l31 >> 1) & 7) = (2 kk) ^ wbase
+  const int wbase = h ^ ((l31 >> 1) & 7);
+  const uint16_t* wsl = Ws + l31 * 64;
   for (int s = 0; s < NS; ++s) {
     const int c = s / NT, t = s - c * NT;
-    r2l_w();
-    if (t == 0) r2l_p();
-    __syncthreads();
+    if (t == 0) {
+      if (s > 0) __syncthreads();   // every wave is past the previous chunk's last MFMAs before its patch is overwritten
+      r2l_p();
+    }
+    __syncthreads();   // tile s has landed (hipcc drains the pending global_load_lds in front of a barrier) and the patch is visible
     if (s + 1 < NS && !MID_ABL(4)) {
       const int c1 = (s + 1) / NT, t1 = (s + 1) - c1 * NT;
-      g2r_w(t1, c1);
       if (t1 == 0) g2r_p(c1);
+      g2l_w(t1, c1, (s + 1) & 1);   // into the buffer stage s - 1 read: all waves finished it before the barrier above
     }
     const uint16_t* bsrc = Ps + trow[t];
+    const uint16_t* wsb = wsl + (s & 1) * 8192;
     if (!MID_ABL(1))
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const uint4 bf = *reinterpret_cast<const uint4*>(bsrc + kk * 16);
+      const int wo = ((2 * kk) ^ wbase) * 8;
       uint4 af[4];
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) af[mt] = *reinterpret_cast<const uint4*>(wsl + mt * 32 * M_PITCH + kk * 16);
+      for (int mt = 0; mt < 4; ++mt) af[mt] = *reinterpret_cast<const uint4*>(wsb + mt * 32 * 64 + wo);
 #pragma unroll
       for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma32<F16>(af[mt], bf, acc[mt]);
     }
-    __syncthreads();
   }
+  __syncthreads();   // the ConvT#1 stage re-uses the patch and weight space
 
   // ---- ConvT#0 epilogue: swish, pack; the packed accumulators are ConvT#1's B operands ----
   // ConvT#1's first operand half is in flight during the swish below
@@ -205,7 +213,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
         a1 = mfma32<F16>(wf, bf, a1);
       }
       uint32_t o[8];
-      swish_pack16<F16>(a1, o);
+      swish_pack16<F16>(a1, o, MID_ABL(16));
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         *reinterpret_cast<uint2*>(stage + l31 * 144 + 64 * jh + 16 * q + 8 * h) = make_uint2(o[2 * q], o[2 * q + 1]);
@@ -217,7 +225,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
           const int pix = (lane >> 3) + 8 * r;
           const int ob = __shfl(obase, pix, 64);
           const uint4 v = *reinterpret_cast<const uint4*>(stage + pix * 144 + (lane & 7) * 16);
-          if (ob >= 0) *reinterpret_cast<uint4*>(p.out + ob + toff + (lane & 7) * 8) = v;
+          if (ob >= 0 && !MID_ABL(8)) *reinterpret_cast<uint4*>(p.out + ob + toff + (lane & 7) * 8) = v;
         }
       }
     }
