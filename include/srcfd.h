@@ -100,6 +100,11 @@ int srcfd_model_get_layer(const srcfd_model* m, int i, srcfd_layer* layer, char*
 int64_t srcfd_model_macs_per_sample(const srcfd_model* m);
 int srcfd_model_set_precision(srcfd_model* m, int precision);
 int srcfd_model_get_precision(const srcfd_model* m);
+/* Allocates now what the first n-sample forward at the CURRENT precision would allocate or pack lazily (activation
+ * workspaces, 16-bit operand packs), so that a latency- or throughput-critical first call does no set-up work.  Optional:
+ * every forward reserves what it needs itself.  The reference pays the equivalent cost inside its first
+ * `predict` (graph tracing, PyCFD_ML_accelerated.py:858). */
+int srcfd_model_reserve(srcfd_model* m, int n);
 /* 1 when the bf16/f16 fused decoder_400 kernels apply to this layer graph. */
 int srcfd_model_has_fused_path(const srcfd_model* m);
 

@@ -94,6 +94,7 @@ _protos = {
     "srcfd_model_macs_per_sample": (C.c_int64, [_p]),
     "srcfd_model_set_precision": (C.c_int, [_p, C.c_int]),
     "srcfd_model_get_precision": (C.c_int, [_p]),
+    "srcfd_model_reserve": (C.c_int, [_p, C.c_int]),
     "srcfd_model_has_fused_path": (C.c_int, [_p]),
     "srcfd_predict": (C.c_int, [_p, _p, C.c_int, _p, _p, _p, C.c_int, C.POINTER(C.c_int64)]),
     "srcfd_predict_device": (C.c_int, [_p, _p, C.c_int, _p, _p, _p, C.c_int, C.c_int, _p, _p]),

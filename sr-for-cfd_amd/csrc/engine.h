@@ -107,6 +107,7 @@ struct Model {
 int fused_init(Model& m);
 void fused_free(Model& m);
 int fused_debug_read(Model& m, int index, void* dst, size_t bytes);
+int fused_reserve(Model& m, int n);
 int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, const float* aff_out, void* y_dev, int out_dtype,
                   int flags, unsigned long long* nonfinite, hipStream_t s);
 

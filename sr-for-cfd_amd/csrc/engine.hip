@@ -748,6 +748,19 @@ int srcfd_model_set_precision(srcfd_model* m, int precision) {
   M(m)->drop_graph();
   return SRCFD_OK;
 }
+int srcfd_model_reserve(srcfd_model* m, int n) {
+  if (!m || n < 0) { set_error("bad arguments"); return SRCFD_EINVAL; }
+  srcfd::Model& mm = *M(m);
+  if (mm.device < 0) { set_error("host-only handle: no device was requested at create"); return SRCFD_ENODEV; }
+  if (n == 0) return SRCFD_OK;
+  HIPCHECK(hipSetDevice(mm.device));
+  if (mm.precision == SRCFD_PREC_BF16 || mm.precision == SRCFD_PREC_F16) {
+    if (!mm.has_fused) { set_error("bf16/f16 precision needs the encoder_10+decoder_400 layer graph; use SRCFD_PREC_FP32 for other graphs"); return SRCFD_EINVAL; }
+    return srcfd::fused_reserve(mm, n);
+  }
+  return mm.ensure_workspace(n);
+}
+
 int srcfd_model_get_precision(const srcfd_model* m) { return m ? M(m)->precision : SRCFD_EINVAL; }
 int srcfd_model_has_fused_path(const srcfd_model* m) { return m ? (int)M(m)->has_fused : 0; }
 

@@ -323,14 +323,14 @@ int fused_debug_read(Model& m, int index, void* dst, size_t bytes) {
 
 static const size_t ACT_ELEMS = 160000;  // largest inter-kernel activation per sample: (50,50,64)
 
-int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, const float* aff_out, void* y_dev, int out_dtype, int flags,
-                  unsigned long long* nonfinite, hipStream_t s) {
+// Everything the 16-bit forward of an n-sample batch allocates or packs lazily: the operand packs of the current operand
+// type and the two activation buffers (+ split-K slabs).  Called by the forward itself and by srcfd_model_reserve.
+int fused_reserve(Model& m, int n) {
   FusedState* fs = m.fused;
   if (!fs) { set_error("fused path not initialised"); return SRCFD_EINVAL; }
   const bool f16 = m.precision == SRCFD_PREC_F16;
   int rc = build_pack(m, fs, f16);
   if (rc) return rc;
-  const Pack16& P = fs->packs[f16 ? 1 : 0];
   const int want = std::min(n, 1024);
   if (want > fs->cap) {
     m.drop_graph();  // a captured forward holds the old buffers' addresses
@@ -342,6 +342,17 @@ int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, cons
     HIPCHECK(hipMalloc(&fs->d_part, fs->part_elems * sizeof(float)));
     fs->cap = want;
   }
+  return SRCFD_OK;
+}
+
+int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, const float* aff_out, void* y_dev, int out_dtype, int flags,
+                  unsigned long long* nonfinite, hipStream_t s) {
+  FusedState* fs = m.fused;
+  if (!fs) { set_error("fused path not initialised"); return SRCFD_EINVAL; }
+  const bool f16 = m.precision == SRCFD_PREC_F16;
+  int rc = fused_reserve(m, n);
+  if (rc) return rc;
+  const Pack16& P = fs->packs[f16 ? 1 : 0];
   const size_t osz = out_dtype == SRCFD_F32 ? 4 : 2;
   for (int i0 = 0; i0 < n; i0 += fs->cap) {
     const int c = std::min(fs->cap, n - i0);

@@ -164,6 +164,10 @@ class SRModel:
     def precision(self, name: str):
         L.check(L.lib.srcfd_model_set_precision(self._h, PRECISIONS[name]))
 
+    def reserve(self, n: int) -> None:
+        """Allocate / pack now what the first n-sample forward at the current precision would set up lazily."""
+        L.check(L.lib.srcfd_model_reserve(self._h, int(n)))
+
     def layers(self) -> List[dict]:
         out = []
         for i in range(L.check(L.lib.srcfd_model_num_layers(self._h))):
