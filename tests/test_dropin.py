@@ -215,6 +215,27 @@ def test_harness_bfs_with_resampling_and_blend_matches_reference_recipe(srcfd, o
 
 
 @pytest.mark.gpu
+def test_reserve_is_the_set_up_a_first_call_would_do(srcfd, enc_weights, dec_weights):
+    """srcfd_model_reserve(n): the lazy set-up of a forward (16-bit operand packs, activation workspaces) done on request;
+    results are those of an unreserved handle, a smaller or repeated reserve is a no-op, a larger one re-allocates."""
+    require_gpu(srcfd)
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal((7, 10, 10, 1)).astype(np.float32)
+    for prec in ("bf16", "fp32"):
+        a = srcfd.SRModel.from_weights(enc_weights, dec_weights, device=0)
+        b = srcfd.SRModel.from_weights(enc_weights, dec_weights, device=0)
+        a.precision = b.precision = prec
+        b.reserve(7)
+        b.reserve(3)
+        b.reserve(0)
+        ya = a.predict(x)
+        np.testing.assert_array_equal(b.predict(x), ya)
+        b.reserve(40)
+        np.testing.assert_array_equal(b.predict(x), ya)
+        np.testing.assert_array_equal(b.predict(np.concatenate([x] * 5))[7:14], ya)
+
+
+@pytest.mark.gpu
 def test_config3_end_to_end_from_a_coarse_bfs_solve_made_here(srcfd, decoder_h5, coarse_cases):
     """BASELINE config 3 without any stored input: coarse backward-facing-step solve (csrc/coarse_solver.cpp, the reference's
     __main__ settings) -> ml_super_resolution with aspect-ratio correction and blend 0.3.  The coarse field is within the

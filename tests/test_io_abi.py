@@ -45,6 +45,10 @@ def test_compute_fails_loudly_without_device(srcfd, enc_weights):
     m = srcfd.SRModel.load_h5(ENCODER_H5, None, device=-1)
     with pytest.raises(srcfd.NoDeviceError):
         m.predict(np.zeros((1, 10, 10, 1), np.float32))
+    with pytest.raises(srcfd.NoDeviceError):
+        m.reserve(4)                     # set-up of device workspaces needs a device, too
+    with pytest.raises(ValueError):
+        m.reserve(-1)
 
 
 def test_precision_switch_rules(srcfd, enc_weights, dec_weights):
