@@ -449,6 +449,12 @@ int Model::forward_generic(const float* x_dev, int n, const float* aff_in, const
       continue;
     }
     static const bool no_big1 = [] { const char* e = getenv("SRCFD_NO_GEMM32_BIG"); return e && atoi(e) != 0; }();
+    static const bool no_skinny = [] { const char* e = getenv("SRCFD_NO_DENSE_SKINNY"); return e && atoi(e) != 0; }();
+    if (!naive && !no_skinny && dense_skinny32_qualifies(d)) {
+      rc = launch(op.name.c_str(), s, [&] { return launch_dense_skinny32(d, X, B, bias, Y, s); });
+      if (rc) return rc;
+      continue;
+    }
     if (!naive && !no_big1 && gemm32_big_qualifies(&d, 1)) {
       rc = launch(op.name.c_str(), s, [&] { return launch_gemm32_big(&d, 1, X, &B, &bias, Y, s); });
       if (rc) return rc;

@@ -32,6 +32,10 @@ struct EpiAux {
 };
 bool gemm_supports_epi_aux(const GemmDesc& d);
 
+// Dense with K <= 52 and N a large multiple of 144 (decoder dense_1), f32: one workgroup per 144 output features (kernels_gemm32.hip)
+bool dense_skinny32_qualifies(const GemmDesc& d);
+hipError_t launch_dense_skinny32(const GemmDesc& d, const float* X, const float* B, const float* bias, float* Y, hipStream_t s);
+
 hipError_t launch_gemm_naive(const GemmDesc& d, const float* X, const float* B, const float* bias, float* Y, hipStream_t s);
 // ws: optional split-K scratch (gemm_splitk_ws_floats(d) floats); without it the launch never splits.
 hipError_t launch_gemm_mfma(const GemmDesc& d, const float* X, const float* B, const float* bias, float* Y, hipStream_t s,

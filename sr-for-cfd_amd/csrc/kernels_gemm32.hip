@@ -212,3 +212,89 @@ hipError_t launch_gemm32_big(const GemmDesc* ds, int count, const float* X, cons
 }
 
 }  // namespace srcfd
+
+namespace srcfd {
+
+// ---------------------------------------------------------------------------
+// dense_skinny32: a Dense layer with a short K and a very wide N (decoder dense_1: 50 -> 36 864, swish; SURVEY.md 8a
+// row a11), f32.  On the generic implicit GEMM this layer took 0.098 ms per 768 samples for 2.8 GFLOP: K is a single
+// shallow slab, so every workgroup was one global-load -> LDS -> MFMA -> store latency chain.  Here a workgroup owns 144
+// output features (36 864 = 256 x 144: one workgroup per CU) for ALL samples: its weights (<= 52 x 144 f32) stay in
+// registers as v_mfma_f32_16x16x4_f32 A operands for the whole kernel, each wave walks 16-sample tiles (B = the input
+// rows, straight from memory / L2), and the activated tile leaves through a wave-private LDS transpose as 576-byte runs
+// per sample.  No workgroup barrier.  Every output column (sample) accumulates over k in the same fixed order whatever the
+// batch: results do not depend on the batch size or on the sample's position.
+// ---------------------------------------------------------------------------
+constexpr int DS_FT = 9, DS_NF = DS_FT * 16, DS_KS = 13, DS_WAVES = 8;   // K <= 4 * DS_KS = 52
+constexpr int DS_PITCH = DS_NF * 4 + 16;                                 // LDS row pitch of the transpose tile, bytes
+constexpr int DS_LDS = DS_WAVES * 16 * DS_PITCH;
+
+__global__ void __launch_bounds__(64 * DS_WAVES, 1) dense_skinny32(GemmDesc d, const float* __restrict__ X, const float* __restrict__ B,
+                                                                    const float* __restrict__ bias, float* __restrict__ Y) {
+  extern __shared__ __attribute__((aligned(16))) char dssm[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = lane & 15, kg = lane >> 4;
+  const int n0 = blockIdx.x * DS_NF, K = d.K, M = d.M, N = d.OC;
+  float wa[DS_FT][DS_KS];
+  f32x4 bs[DS_FT];
+#pragma unroll
+  for (int ft = 0; ft < DS_FT; ++ft) {
+#pragma unroll
+    for (int ks = 0; ks < DS_KS; ++ks) {
+      const int k = ks * 4 + kg;
+      wa[ft][ks] = k < K ? B[(size_t)k * d.Npad + n0 + ft * 16 + col] : 0.f;
+    }
+    bs[ft] = *reinterpret_cast<const f32x4*>(bias + n0 + ft * 16 + kg * 4);
+  }
+  char* st = dssm + wave * 16 * DS_PITCH;
+  const int tiles = (M + 15) / 16;
+  const bool swish = d.act == SRCFD_ACT_SWISH;
+  for (int t = wave; t < tiles; t += DS_WAVES) {
+    const int sv = min(t * 16 + col, M - 1);
+    float xb[DS_KS];
+#pragma unroll
+    for (int ks = 0; ks < DS_KS; ++ks) {
+      const int k = ks * 4 + kg;
+      xb[ks] = k < K ? X[(size_t)sv * K + k] : 0.f;
+    }
+#pragma unroll
+    for (int ft = 0; ft < DS_FT; ++ft) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < DS_KS; ++ks) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[ft][ks], xb[ks], acc, 0, 0, 0);
+      acc += bs[ft];
+      if (swish) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = gb_swish(acc[r]);
+      }
+      *reinterpret_cast<f32x4*>(st + col * DS_PITCH + ft * 64 + kg * 16) = acc;
+    }
+    // write-out: 16 samples x 36 chunks of 16 B, consecutive lanes on consecutive chunks of one sample's 576-byte run
+#pragma unroll
+    for (int r = 0; r < 16 * DS_NF / 4 / 64; ++r) {
+      const int c = lane + 64 * r, row = c / (DS_NF / 4), ch = c - row * (DS_NF / 4), s = t * 16 + row;
+      if (s < M) *reinterpret_cast<f32x4*>(Y + (size_t)s * N + n0 + ch * 4) = *reinterpret_cast<const f32x4*>(st + row * DS_PITCH + ch * 16);
+    }
+  }
+}
+
+bool dense_skinny32_qualifies(const GemmDesc& d) {
+  return d.MH == 1 && d.MW == 1 && d.TY == 1 && d.TX == 1 && d.K <= 4 * DS_KS && d.CI == d.K && d.N == d.Npad && d.N % DS_NF == 0 && d.OC == d.N &&
+         d.N >= 64 * DS_NF && (d.act == SRCFD_ACT_SWISH || d.act == SRCFD_ACT_LINEAR);
+}
+
+hipError_t launch_dense_skinny32(const GemmDesc& d, const float* X, const float* B, const float* bias, float* Y, hipStream_t s) {
+  if (d.M == 0) return hipSuccess;
+  static thread_local int attr_dev = -1;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  if (attr_dev != dev) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(dense_skinny32), hipFuncAttributeMaxDynamicSharedMemorySize, DS_LDS);
+    if (e != hipSuccess) return e;
+    attr_dev = dev;
+  }
+  hipLaunchKernelGGL(dense_skinny32, dim3(d.N / DS_NF), dim3(64 * DS_WAVES), DS_LDS, s, d, X, B, bias, Y);
+  return hipGetLastError();
+}
+
+}  // namespace srcfd
