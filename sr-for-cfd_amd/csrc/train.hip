@@ -360,13 +360,30 @@ static void launch_wgrad(const GemmDesc& d, const WgradPlan& p, const float* X, 
 // grads[map[i]-1] += sum_slices part[slice][i]   for the (K+1) x Npad elements of one op.  In the bias
 // row of a merged-phase op (kernel == stride transposed conv) the N/CO phase columns of one channel
 // all map to the same parameter: the thread of phase 0 sums them in phase order (no atomics).
-__global__ void __launch_bounds__(256) wgrad_finish_f32(const float* __restrict__ part, int nslices, int64_t elems, const int* __restrict__ map,
-                                                         float* __restrict__ grads, int K, int N, int Npad, int CO, int groups) {
+// One launch sums the slabs of ALL ops of a step (every op keeps its slabs in space of its own until then): as fourteen
+// launches of 2-26 us these sums were 150 us of the weight-gradient stream's 395 us, and that stream was the step's critical
+// path.  The table travels as a kernel argument (it depends on the batch size through the slab counts).
+struct FinishOp {
+  const float* part; const int* map; int64_t elems;
+  int nslices, K, N, Npad, CO, groups, block0;   // block0: first workgroup of this op in the merged grid
+};
+constexpr int MAX_FINISH_OPS = 24;
+struct FinishTable { FinishOp op[MAX_FINISH_OPS]; int nops; };
+
+__global__ void __launch_bounds__(256) wgrad_finish_all_f32(const FinishTable tab, float* __restrict__ grads) {
+  int oi = 0;
+  while (oi + 1 < tab.nops && (int)blockIdx.x >= tab.op[oi + 1].block0) ++oi;   // block-uniform: scalar compares on the kernel arguments
+  const FinishOp& o = tab.op[oi];
+  const float* __restrict__ part = o.part;
+  const int* __restrict__ map = o.map;
+  const int64_t elems = o.elems;
+  const int nslices = o.nslices, K = o.K, N = o.N, Npad = o.Npad, CO = o.CO, groups = o.groups;
+  const int blk = (int)blockIdx.x - o.block0;
   // (256 / groups) consecutive elements x `groups` slab groups per block; group g adds slabs g, g+groups, ...
   // (four independent chains so the loads overlap); the groups are then added in order.
   __shared__ float red[256];
   const int epb = 256 / groups, e = threadIdx.x % epb, g = threadIdx.x / epb;
-  const int64_t i = (int64_t)blockIdx.x * epb + e;
+  const int64_t i = (int64_t)blk * epb + e;
   int k = 0;
   float s = 0.f;
   if (i < elems) {
@@ -412,6 +429,7 @@ struct TrainOp {
   // wgrad
   std::vector<int> gmap;  // (K+1) x Npad -> flat param index + 1 (0: padding)
   int* d_gmap = nullptr;
+  size_t part_off = 0, part_cap = 0;   // this op's own slab space in Trainer::d_part (floats)
 };
 
 struct DgradOp {
@@ -446,6 +464,10 @@ struct Trainer {
   // data-gradient chain, so they run on a second stream beside it (at micro-batch sizes no kernel fills the chip).
   hipStream_t aux = nullptr;
   std::vector<hipEvent_t> ev_dz, ev_wg;            // per layer: dZ ready (main stream) / weight gradient done (aux)
+  // (A third stream for the slab sums was tried: two forked streams that wait on each other send hipStreamEndCapture into an
+  // endless recursion on ROCm 7.2, and with one-way dependencies the three-branch graph replayed level by level, 0.83 ms
+  // against 0.72 for two branches.  The sums are ONE launch at the end of the aux stream instead: wgrad_finish_all_f32.)
+  hipEvent_t ev_fin = nullptr;                     // end of the aux stream's work of the step
   bool overlap = true;                             // SRCFD_TRAIN_OVERLAP=0: everything on the caller's stream
   // A step is ~100 launches and event operations of 5-40 us kernels: issued one by one the host cannot keep the device
   // fed (20 % of the step was idle gaps).  The second time a step with the same buffers and batch size is asked for it is
@@ -472,6 +494,7 @@ Trainer::~Trainer() {
   for (auto& g : graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
   if (cap_stream) (void)hipStreamDestroy(cap_stream);
   if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); }
+  if (ev_fin) (void)hipEventDestroy(ev_fin);
   if (d_xs) (void)hipFree(d_xs);
   if (d_ys) (void)hipFree(d_ys);
   for (hipEvent_t e : ev_dz) (void)hipEventDestroy(e);
@@ -589,7 +612,7 @@ static int trainer_build(Trainer& t, const Model& model, int max_batch) {
   int rc = upload_map(ipack, &t.d_pack_map);
   if (rc) return rc;
   HIPCHECK(hipMalloc(&t.d_pack, t.pack_elems * sizeof(float)));
-  size_t part_need = 1;
+  size_t part_need = 0;   // every op has slab space of its own: the sum of one op never has to finish before the next op's slabs are written
   for (const Op& op : iops) {
     TrainOp to;
     to.fwd = op.d;
@@ -606,12 +629,16 @@ static int trainer_build(Trainer& t, const Model& model, int max_batch) {
     for (int n = 0; n < d.N; ++n) to.gmap[(size_t)d.K * d.Npad + n] = (int)ipack[op.b_off + n];
     HIPCHECK(hipMalloc(&to.d_gmap, to.gmap.size() * sizeof(int)));
     HIPCHECK(hipMemcpy(to.d_gmap, to.gmap.data(), to.gmap.size() * sizeof(int), hipMemcpyHostToDevice));
+    size_t op_need = 1;
     for (int b = 1; b <= max_batch; ++b) {  // the slab count is not monotonic in the batch
       GemmDesc db = d;
       db.M = b * d.MH * d.MW;
       WgradPlan wp = wgrad_plan(db);
-      part_need = std::max(part_need, (size_t)wp.nslices * to.gmap.size());
+      op_need = std::max(op_need, (size_t)wp.nslices * to.gmap.size());
     }
+    to.part_off = part_need;
+    to.part_cap = op_need;
+    part_need += (op_need + 63) / 64 * 64;
     t.ops.push_back(std::move(to));
   }
   t.part_elems = part_need;
@@ -651,6 +678,7 @@ static int trainer_build(Trainer& t, const Model& model, int max_batch) {
   }
   if (t.overlap) {
     HIPCHECK(hipStreamCreateWithFlags(&t.aux, hipStreamNonBlocking));
+    HIPCHECK(hipEventCreateWithFlags(&t.ev_fin, hipEventDisableTiming));
     for (size_t i = 0; i < t.layers.size(); ++i) {
       hipEvent_t a, b;
       HIPCHECK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
@@ -722,6 +750,11 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
   //    gradients, each waiting only for its layer's dZ.  dZ buffers rotate through a ring of three, so the data-gradient
   //    chain may run two layers ahead of the weight gradients before it has to wait for one of them.
   int cur = 0;
+  int wseq = 0;          // weight-gradient ops issued so far in this step
+  constexpr int MAX_FINISH_GROUPS = 4;
+  int fblocks[MAX_FINISH_GROUPS] = {0, 0, 0, 0};       // workgroups of the merged slab-sum launches so far
+  FinishTable ftab[MAX_FINISH_GROUPS];
+  for (auto& ft : ftab) ft.nops = 0;
   bool dz_done = false;  // the data-gradient GEMM below already multiplied by swish'(Z) of the layer it feeds (EpiAux mode 2)
   hipStream_t ws = t.overlap ? t.aux : s;
   for (int li = L - 1; li >= 0; --li) {
@@ -734,17 +767,27 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
       HIPCHECK(hipStreamWaitEvent(t.aux, t.ev_dz[li], 0));
     }
     const float* X = li == 0 ? x : t.Y[li - 1];
+    int in_layer = 0;
     for (const TrainOp& op : t.ops) {
       if (op.layer != li) continue;
       GemmDesc d = op.fwd;
       d.M = n * d.MH * d.MW;
       const WgradPlan wp = wgrad_plan(d);
       const int64_t elems = (int64_t)(d.K + 1) * d.Npad;
-      if ((size_t)wp.nslices * elems > t.part_elems) { set_error("training: gradient slab buffer too small"); return SRCFD_EINVAL; }
-      launch_wgrad(d, wp, X, dZ, t.d_part, ws);
+      if ((size_t)wp.nslices * elems > op.part_cap) { set_error("training: gradient slab buffer too small"); return SRCFD_EINVAL; }
+      float* part = t.d_part + op.part_off;
+      launch_wgrad(d, wp, X, dZ, part, ws);
       const int groups = wp.nslices >= 256 ? 32 : (wp.nslices >= 64 ? 8 : (wp.nslices >= 8 ? 4 : 1)), epb = 256 / groups;
-      hipLaunchKernelGGL(wgrad_finish_f32, dim3((unsigned)((elems + epb - 1) / epb)), dim3(256), 0, ws, t.d_part, wp.nslices, elems, op.d_gmap, grads,
-                         d.K, d.N, d.Npad, d.CO, groups);
+      // ops of one layer (the output phases of ConvT#0) add into the SAME bias parameters: the q-th op of every layer goes
+      // into merged launch q, and the launches of one stream run one after the other
+      if (in_layer >= MAX_FINISH_GROUPS || ftab[in_layer].nops >= MAX_FINISH_OPS) { set_error("training: more weight-gradient ops than the finish tables hold"); return SRCFD_EINVAL; }
+      FinishTable& ft = ftab[in_layer];
+      FinishOp& fo = ft.op[ft.nops++];
+      fo.part = part; fo.map = op.d_gmap; fo.elems = elems; fo.nslices = wp.nslices; fo.K = d.K; fo.N = d.N; fo.Npad = d.Npad; fo.CO = d.CO;
+      fo.groups = groups; fo.block0 = fblocks[in_layer];
+      fblocks[in_layer] += (int)((elems + epb - 1) / epb);
+      ++in_layer;
+      ++wseq;
     }
     if (t.overlap) HIPCHECK(hipEventRecord(t.ev_wg[li], t.aux));
     if (li > 0) {
@@ -760,7 +803,12 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
       cur = nxt;
     }
   }
-  if (t.overlap) HIPCHECK(hipStreamWaitEvent(s, t.ev_wg[0], 0));  // aux is in order: layer 0's event covers all of them
+  for (int q = 0; q < MAX_FINISH_GROUPS; ++q)   // all slabs are written (ws is in order): the merged launches sum them into grads
+    if (ftab[q].nops > 0) hipLaunchKernelGGL(wgrad_finish_all_f32, dim3((unsigned)fblocks[q]), dim3(256), 0, ws, ftab[q], grads);
+  if (t.overlap) {
+    HIPCHECK(hipEventRecord(t.ev_fin, t.aux));
+    HIPCHECK(hipStreamWaitEvent(s, t.ev_fin, 0));  // aux is in order: this covers all of its kernels
+  }
   HIPCHECK(hipGetLastError());
   return SRCFD_OK;
 }
