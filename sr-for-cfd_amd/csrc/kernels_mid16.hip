@@ -104,12 +104,20 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
   // Weight tiles go global -> LDS directly (global_load_lds: no registers, no ds_write pass), two buffers.  The LDS image
   // is lane-linear (chunk index = row * 8 + slot = tid + NTHR * j), so the bank swizzle sits on the SOURCE address: slot
   // `sl` of row r holds k-chunk sl ^ ((r >> 1) & 7), and the fragment reads below apply the same XOR.
+  // The builtin form of the instruction is known to hipcc as a pending LDS write: it then puts `s_waitcnt vmcnt(0)` in front of
+  // the next ds_read -- here the fragment reads of the tile being COMPUTED -- which drains the prefetch before the MFMAs start
+  // (seen in the ISA; the kernel gained nothing from the prefetch).  As an asm statement the load is outside hipcc's
+  // bookkeeping: the stage loop waits for it itself (vmcnt(0) in front of the barrier that publishes the tile).
+  const unsigned lds_w0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(msm + C::OFF_W);
   auto g2l_w = [&](int t, int c, int buf) {
 #pragma unroll
     for (int j = 0; j < C::WCH; ++j) {
       const int r = xrow + RSTEP * j;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wt + r * Kp + t * 256 + c * 64 + ((c8 ^ ((r >> 1) & 7)) * 8)),
-                                       (__attribute__((address_space(3))) void*)(msm + C::OFF_W + buf * 16384 + (size_t)(wave * 64 + C::NTHR * j) * 16), 16, 0, 0);
+      const uint16_t* src = Wt + r * Kp + t * 256 + c * 64 + ((c8 ^ ((r >> 1) & 7)) * 8);
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_w0 + (unsigned)(buf * 16384 + (wave * 64 + C::NTHR * j) * 16));
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
     }
   };
   auto g2r_p = [&](int c) {
@@ -156,7 +164,8 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
       if (s > 0) __syncthreads();   // every wave is past the previous chunk's last MFMAs before its patch is overwritten
       r2l_p();
     }
-    __syncthreads();   // tile s has landed (hipcc drains the pending global_load_lds in front of a barrier) and the patch is visible
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile s (asm global_load_lds, issued a stage ago) has landed in this wave's share
+    __syncthreads();   // ... and in everybody's; the patch is visible
     if (s + 1 < NS && !MID_ABL(4)) {
       const int c1 = (s + 1) / NT, t1 = (s + 1) - c1 * NT;
       if (t1 == 0) g2r_p(c1);
