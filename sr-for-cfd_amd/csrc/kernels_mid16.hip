@@ -135,10 +135,17 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
   static_assert(W1CH * C::NTHR == 2048, "a half of ConvT#1's operands divides evenly over the workgroup");
   const u32x4* w1g = reinterpret_cast<const u32x4*>(p.w1f);
   auto g2l_w1 = [&](int half) {   // lane-linear LDS image: wave w's j-th instruction fills chunks (w*64 + NTHR*j) .. +63
+    // (asm, like the weight tiles above: with the builtin pending, hipcc put vmcnt(0) in front of every tile's first LDS read in
+    // the ConvT#1 loop, and that counter also holds the previous tap's global stores -- each tile waited for them to complete)
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)msm;
 #pragma unroll
-    for (int j = 0; j < W1CH; ++j)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w1g + half * 2048 + tid + C::NTHR * j),
-                                       (__attribute__((address_space(3))) void*)(msm + (size_t)(wave * 64 + C::NTHR * j) * 16), 16, 0, 0);
+    for (int j = 0; j < W1CH; ++j) {
+      const u32x4* src = w1g + half * 2048 + tid + C::NTHR * j;
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((wave * 64 + C::NTHR * j) * 16));
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+    }
   };
   auto r2l_p = [&]() {
 #pragma unroll
@@ -204,16 +211,21 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
   const int Y = 2 * my + py, X = 2 * mx + px;  // 25x25-level pixel
   const int obase = img >= 0 ? ((img * 50 + 2 * Y) * 50 + 2 * X) * 64 : -1;  // element offset of tap (0,0)
   if (!MID_ABL(2)) {
-    __syncthreads();   // (drains the global_load_lds above: hipcc puts vmcnt(0) in front of a barrier while one is in flight)
+    // ConvT#1's bias fragments go to LDS (the row tables there are dead): read from memory at the top of every tile they made
+    // the tile's first MFMA wait on vmcnt -- an in-order counter that also holds the previous tap's global stores
+    if (tid < 64) reinterpret_cast<float*>(msm + C::OFF_META)[tid] = p.b1f[tid];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the first operand half has landed
+    __syncthreads();
 #pragma unroll 1
     for (int jj = 0; jj < 8; ++jj) {
       const int tap = jj >> 1, jh = jj & 1;
       if (jj == 4) {   // second half: the only point of the stage where the waves meet (its load latency is exposed once)
         __syncthreads();
         g2l_w1(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
       }
-      f32x16 a1 = load_bias16(reinterpret_cast<const char*>(p.b1f) + (jh * 2 + h) * 64);
+      f32x16 a1 = load_bias16(msm + C::OFF_META + (jh * 2 + h) * 64);
       const uint4* wt = w1s + (jj & 3) * 512 + lane;
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
