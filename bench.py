@@ -504,7 +504,6 @@ def main():
                 y_gpu["fp32"] = y_par[:8].cpu().numpy()
             return rec
         parity = leg("parity_path", _parity)
-        torch.cuda.empty_cache()
 
     head, y_head = job.run_sr(args.precision, args.out_dtype, args.steps, args.warmup)
     if job.rank == 0 and job.world == 1 and not args.no_cpu_baseline and args.out_dtype == "f32":
