@@ -49,6 +49,9 @@ struct Model {
   // ops[tail32_op .. +3]: that chain followed by the network's last layer, a 3x3 SAME conv 8 -> 1 (kernels.h, Tail32Params):
   // one streaming kernel; takes precedence over the triple
   int tail32_op = -1;
+  // ops[0..3] = conv2d (1->64, s2) -> conv2d_1 (64->128 on 5x5) -> dense (3200->128) -> latent (128->nl) run as one launch (kernels.h, Enc32Params)
+  bool enc32_ok = false;
+  size_t enc32_w2 = 0;     // conv2d_1 A fragments in `pack`
   size_t t32_w1 = 0, t32_b1 = 0, t32_w2 = 0, t32_b2 = 0, t32_w3 = 0, t32_b3 = 0, t32_wc = 0;
   int num_cus = 256;
   float* d_pack = nullptr;

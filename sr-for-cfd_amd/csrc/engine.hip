@@ -248,6 +248,37 @@ static void plan_tail32(Model& m) {
   m.tail32_op = (int)i;
 }
 
+// enc32 (kernels_enc32.hip): the encoder's four compute layers as one launch.  conv2d_1's weights are re-ordered into
+// v_mfma_f32_16x16x4_f32 A fragments: frag[((w*36 + tap*4 + q)*64 + lane)*4 + j] = W[tap][ci = 16 q + 4 (lane / 16) + j][co = 16 w + lane % 16]
+// (Keras Conv2D kernel (kh, kw, cin, cout)); the other three layers use their ordinary B[K][Npad] operands.
+static void plan_enc32(Model& m) {
+  m.enc32_ok = false;
+  if (m.ops.size() < 5 || m.desc.in_shape[0] != 10 || m.desc.in_shape[1] != 10 || m.desc.in_shape[2] != 1) return;
+  for (int i = 0; i < 4; ++i) if (m.ops[i + 1].layer == m.ops[i].layer) return;   // one op per layer
+  const GemmDesc &c1 = m.ops[0].d, &c2 = m.ops[1].d, &de = m.ops[2].d, &la = m.ops[3].d;
+  const Layer &L0 = m.desc.layers[m.ops[0].layer], &L1 = m.desc.layers[m.ops[1].layer];
+  auto act_ok = [](int a) { return a == SRCFD_ACT_SWISH || a == SRCFD_ACT_LINEAR; };
+  if (L0.kind != SRCFD_LAYER_CONV2D || L0.kh != 3 || L0.kw != 3 || L0.stride != 2 || !L0.same || L0.cin != 1 || L0.cout != 64 || c1.Npad != 64) return;
+  if (L1.kind != SRCFD_LAYER_CONV2D || L1.kh != 3 || L1.kw != 3 || L1.stride != 1 || !L1.same || L1.cin != 64 || L1.cout != 128 || c2.MH != 5 || c2.MW != 5) return;
+  if (de.MH != 1 || de.MW != 1 || de.K != 3200 || de.N != 128 || de.Npad != 128) return;
+  if (la.MH != 1 || la.MW != 1 || la.K != 128 || la.N > 128 || la.OC != la.N) return;
+  if (!act_ok(c1.act) || !act_ok(c2.act) || !act_ok(de.act) || !act_ok(la.act)) return;
+  auto& pk = m.pack;
+  while (pk.size() % 64) pk.push_back(0.f);
+  m.enc32_w2 = pk.size();
+  pk.resize(pk.size() + (size_t)8 * 36 * 64 * 4);
+  for (int w = 0; w < 8; ++w)
+    for (int tap = 0; tap < 9; ++tap)
+      for (int q = 0; q < 4; ++q)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 4; ++j) {
+            const int ci = 16 * q + 4 * (lane >> 4) + j, co = 16 * w + (lane & 15);
+            pk[m.enc32_w2 + ((size_t)((w * 36 + tap * 4 + q) * 64 + lane)) * 4 + j] = L1.kernel[((size_t)tap * 64 + ci) * 128 + co];
+          }
+  while (pk.size() % 64) pk.push_back(0.f);
+  m.enc32_ok = true;
+}
+
 // ---------------------------------------------------------------------------
 // model
 // ---------------------------------------------------------------------------
@@ -373,10 +404,30 @@ int Model::forward_generic(const float* x_dev, int n, const float* aff_in, const
   const int out_elems = os[0] * os[1] * os[2];
   const bool naive = precision == SRCFD_PREC_FP32_NAIVE;
   int cur = 0;
-  int rc = launch("standardize", s, [&] { return launch_standardize(x_dev, buf[0], aff_in, in_elems, (int64_t)n * in_elems, s); });
-  if (rc) return rc;
+  int rc = SRCFD_OK;
   int prev_layer = -1;
-  for (size_t i = 0; i < ops.size(); ++i) {
+  size_t first = 0;
+  static const bool no_enc32 = [] { const char* e = getenv("SRCFD_NO_ENC32"); return e && atoi(e) != 0; }();
+  if (enc32_ok && !naive && !no_enc32) {   // standardise + the encoder's four layers: one launch, latent vectors into buf[0]
+    Enc32Params ep;
+    ep.x = x_dev; ep.affine = aff_in; ep.n = n;
+    ep.w1 = d_pack + ops[0].w_off; ep.b1 = d_pack + ops[0].b_off;
+    ep.w2f = d_pack + enc32_w2; ep.b2 = d_pack + ops[1].b_off;
+    ep.wd = d_pack + ops[2].w_off; ep.bd = d_pack + ops[2].b_off;
+    ep.wl = d_pack + ops[3].w_off; ep.bl = d_pack + ops[3].b_off;
+    ep.z = buf[0];
+    ep.nl = ops[3].d.N; ep.nl_pad = ops[3].d.Npad;
+    ep.act1 = ops[0].d.act; ep.act2 = ops[1].d.act; ep.act3 = ops[2].d.act; ep.act4 = ops[3].d.act;
+    rc = launch("encoder(standardize..latent_vector)", s, [&] { return launch_enc32(ep, s); });
+    if (rc) return rc;
+    first = 4;
+    prev_layer = ops[3].layer;
+    cur = 1;          // the next op is a new layer: it flips to buf[0], where the latent vectors are
+  } else {
+    rc = launch("standardize", s, [&] { return launch_standardize(x_dev, buf[0], aff_in, in_elems, (int64_t)n * in_elems, s); });
+    if (rc) return rc;
+  }
+  for (size_t i = first; i < ops.size(); ++i) {
     const Op& op = ops[i];
     if (op.layer != prev_layer && prev_layer >= 0) cur ^= 1;
     prev_layer = op.layer;
@@ -586,6 +637,7 @@ static int finish_create(std::unique_ptr<Model>& m, srcfd_model** out) {
     plan_convt_pair(*m);
     plan_convt_triple(*m);
     plan_tail32(*m);
+    plan_enc32(*m);
   } catch (const std::exception& e) {
     set_error(e.what());
     return SRCFD_EINVAL;

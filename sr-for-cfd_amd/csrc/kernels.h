@@ -32,6 +32,22 @@ struct EpiAux {
 };
 bool gemm_supports_epi_aux(const GemmDesc& d);
 
+// The whole encoder_10 in one launch, f32 (kernels_enc32.hip)
+constexpr int ENC32_G = 3;   // samples per workgroup
+struct Enc32Params {
+  const float* x;          // (n,10,10,1) f32
+  const float* affine;     // (n,2) mean,std or null
+  int n;
+  const float* w1; const float* b1;     // conv2d: B[9][64], bias[64]
+  const float* w2f; const float* b2;    // conv2d_1: A fragments [channel tile 8][tap*4+q 36][64 lanes][4] (engine.hip, plan_enc32), bias[128]
+  const float* wd; const float* bd;     // dense: B[3200][128], bias[128]
+  const float* wl; const float* bl;     // latent_vector: B[128][nl_pad], bias[nl]
+  float* z;                             // (n, nl)
+  int nl, nl_pad;
+  int act1, act2, act3, act4;
+};
+hipError_t launch_enc32(const Enc32Params& p, hipStream_t s);
+
 // Dense with K <= 52 and N a large multiple of 144 (decoder dense_1), f32: one workgroup per 144 output features (kernels_gemm32.hip)
 bool dense_skinny32_qualifies(const GemmDesc& d);
 hipError_t launch_dense_skinny32(const GemmDesc& d, const float* X, const float* B, const float* bias, float* Y, hipStream_t s);

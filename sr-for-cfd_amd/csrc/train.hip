@@ -750,7 +750,6 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
   //    gradients, each waiting only for its layer's dZ.  dZ buffers rotate through a ring of three, so the data-gradient
   //    chain may run two layers ahead of the weight gradients before it has to wait for one of them.
   int cur = 0;
-  int wseq = 0;          // weight-gradient ops issued so far in this step
   constexpr int MAX_FINISH_GROUPS = 4;
   int fblocks[MAX_FINISH_GROUPS] = {0, 0, 0, 0};       // workgroups of the merged slab-sum launches so far
   FinishTable ftab[MAX_FINISH_GROUPS];
@@ -787,7 +786,6 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
       fo.groups = groups; fo.block0 = fblocks[in_layer];
       fblocks[in_layer] += (int)((elems + epb - 1) / epb);
       ++in_layer;
-      ++wseq;
     }
     if (t.overlap) HIPCHECK(hipEventRecord(t.ev_wg[li], t.aux));
     if (li > 0) {
