@@ -50,6 +50,35 @@ def test_encoder_latents_real_weights(srcfd, oracle, enc_weights, coarse_cases, 
     assert oracle.rel_l2(z.reshape(15, -1), ref) <= TOL_FP32
 
 
+def test_one_launch_f32_encoder_against_the_layer_by_layer_launches(srcfd, oracle, enc_weights, dec_weights, coarse_cases, monkeypatch):
+    """enc32 (standardise + conv2d + conv2d_1 + dense + latent_vector in one kernel, 3 samples per workgroup) and dense_skinny32
+    (dense_1) against the generic launches they replace (SRCFD_NO_ENC32 / SRCFD_NO_DENSE_SKINNY): both inside the 1e-5 bar, within
+    f32 rounding of each other, rows independent of the batch (partial last workgroups), fused standardisation bitwise equal to
+    standardising first."""
+    require_gpu(srcfd)
+    x = _coarse_batch(coarse_cases, srcfd)
+    ref = oracle.superres_forward(x[:6], enc_weights, dec_weights, np.float64)
+    m = srcfd.SRModel.from_weights(enc_weights, dec_weights, device=0)
+    y_new = m.predict(x[:6])
+    monkeypatch.setenv("SRCFD_NO_ENC32", "1")
+    monkeypatch.setenv("SRCFD_NO_DENSE_SKINNY", "1")
+    y_old = m.predict(x[:6])
+    monkeypatch.delenv("SRCFD_NO_ENC32")
+    monkeypatch.delenv("SRCFD_NO_DENSE_SKINNY")
+    assert oracle.rel_l2(y_new, ref) <= TOL_FP32 and oracle.rel_l2(y_old, ref) <= TOL_FP32
+    assert oracle.rel_l2(y_new, y_old) <= 2e-6
+    # the encoder alone (latent vectors) on the same kernel
+    enc = srcfd.SRModel.load_h5(ENCODER_H5, None, device=0)
+    z = enc.predict(x)
+    assert oracle.rel_l2(z.reshape(15, -1), oracle.encoder_forward(x, enc_weights, np.float64)) <= TOL_FP32
+    for lo, hi in ((0, 1), (1, 3), (3, 7), (2, 15), (14, 15)):
+        np.testing.assert_array_equal(enc.predict(x[lo:hi]), z[lo:hi])
+    rng = np.random.default_rng(8)
+    ain = np.stack([rng.standard_normal(15) * 0.1, rng.uniform(0.5, 2.0, 15)], 1).astype(np.float32)
+    xn = ((x - ain[:, 0].reshape(15, 1, 1, 1)) / ain[:, 1].reshape(15, 1, 1, 1)).astype(np.float32)
+    np.testing.assert_array_equal(enc.predict(x, in_affine=ain), enc.predict(xn))
+
+
 LAYER_CASES = [
     # name, spec builder args: kind, k, stride, same, cin, cout, in_hw
     ("conv_same_s2_asym_pad", "conv2d", 3, 2, True, 1, 64, (10, 10)),
