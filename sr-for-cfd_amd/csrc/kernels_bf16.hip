@@ -456,6 +456,43 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
   unsigned long long tD = 0, tBC = 0, tA = 0, tBar = 0, tStart = 0, ts[6];
   if (PROF) tStart = __builtin_amdgcn_s_memtime();
   for (int r = 0; r <= G + 2 && K > 0; ++r) {
+    // ---------------- A: ConvT#2 for strip g = r (input prefetched last round), then prefetch g+1 ----------------
+    // Runs BEFORE this wave's D items (waves 0-7: BC -> A -> D).  vmcnt is one in-order counter for loads and stores: waiting
+    // for the prefetched input right after D's global stores (the old order BC -> D -> A) made the wave sit out the completion
+    // of stores it had issued a few hundred cycles earlier, at the end of every round, in front of the barrier.  With A first
+    // the youngest operations ahead of the wait are last round's stores -- long done -- and this round's stores have until
+    // the next round's A.
+    auto run_a = [&]() {
+      int a_smp = 0, a_s = -1, a_sg = 0, a_sl = 0;
+      if (r < G) strip_of(r, a_smp, a_s, a_sg, a_sl);
+      if (hasA && r < G && !TAIL_ABL(4)) {
+        int n_smp = 0, n_s = -1, n_sg = 0, n_sl = 0;
+        if (r + 1 < G) strip_of(r + 1, n_smp, n_s, n_sg, n_sl);
+        if (a_s < 0) {        // warm-up strip above the image: nothing to compute, only fetch the next strip's input
+          if (n_s >= 0) {
+            const uint16_t* src = p.in + ((size_t)n_smp * 50 + n_s) * 3200 + a_lane;
+  #pragma unroll
+            for (int kk = 0; kk < 4; ++kk) xb[kk] = *reinterpret_cast<const uint4*>(src + 16 * kk);
+          }
+        } else {
+        f32x16 acc = load_bias16(cst + TC_OFF_B2 + h * 64);
+  #pragma unroll
+        for (int kk = 0; kk < 4; ++kk) acc = mfma32<F16>(wa[kk], xb[kk], acc);
+        if (n_s >= 0) {
+          const uint16_t* src = p.in + ((size_t)n_smp * 50 + n_s) * 3200 + a_lane;
+  #pragma unroll
+          for (int kk = 0; kk < 4; ++kk) xb[kk] = *reinterpret_cast<const uint4*>(src + 16 * kk);
+        }
+        uint32_t f2[8];
+        swish_pack16<F16>(acc, f2, ab_sw);
+        if (a_valid) {
+          char* dst = l100 + (r & 1) * T_L100_BUF + a_dst;
+  #pragma unroll
+          for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(dst + q * (212 * 16)) = make_uint2(f2[2 * q], f2[2 * q + 1]);
+        }
+        }
+      }
+    };
     // ---------------- BC: ConvT#3 + ConvT#4 on 32 pixels of the 100-level ----------------
     auto do_bc = [&]() {
       const int g = r - 1;
@@ -674,43 +711,15 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
       do_bc();
       if (PROF) ts[2] = __builtin_amdgcn_s_memtime();
       if (!d_first_order) {
+        run_a();
         if (!TAIL_ABL(128)) __builtin_amdgcn_s_setprio(3);
         run_d();
         __builtin_amdgcn_s_setprio(0);
       }
       if (PROF) ts[3] = __builtin_amdgcn_s_memtime();
+      if (d_first_order) run_a();   // (waves 8-15 have no A items; the diagnostic orders keep the call)
     }
 
-    // ---------------- A: ConvT#2 for strip g = r (input prefetched last round), then prefetch g+1 ----------------
-    int a_smp = 0, a_s = -1, a_sg = 0, a_sl = 0;
-    if (r < G) strip_of(r, a_smp, a_s, a_sg, a_sl);
-    if (hasA && r < G && !TAIL_ABL(4)) {
-      int n_smp = 0, n_s = -1, n_sg = 0, n_sl = 0;
-      if (r + 1 < G) strip_of(r + 1, n_smp, n_s, n_sg, n_sl);
-      if (a_s < 0) {        // warm-up strip above the image: nothing to compute, only fetch the next strip's input
-        if (n_s >= 0) {
-          const uint16_t* src = p.in + ((size_t)n_smp * 50 + n_s) * 3200 + a_lane;
-#pragma unroll
-          for (int kk = 0; kk < 4; ++kk) xb[kk] = *reinterpret_cast<const uint4*>(src + 16 * kk);
-        }
-      } else {
-      f32x16 acc = load_bias16(cst + TC_OFF_B2 + h * 64);
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) acc = mfma32<F16>(wa[kk], xb[kk], acc);
-      if (n_s >= 0) {
-        const uint16_t* src = p.in + ((size_t)n_smp * 50 + n_s) * 3200 + a_lane;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) xb[kk] = *reinterpret_cast<const uint4*>(src + 16 * kk);
-      }
-      uint32_t f2[8];
-      swish_pack16<F16>(acc, f2, ab_sw);
-      if (a_valid) {
-        char* dst = l100 + (r & 1) * T_L100_BUF + a_dst;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) *reinterpret_cast<uint2*>(dst + q * (212 * 16)) = make_uint2(f2[2 * q], f2[2 * q + 1]);
-      }
-      }
-    }
     if (PROF) ts[4] = __builtin_amdgcn_s_memtime();
     lds_barrier();
     if (PROF) {
