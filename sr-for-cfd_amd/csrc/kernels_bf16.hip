@@ -462,7 +462,9 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
     // of stores it had issued a few hundred cycles earlier, at the end of every round, in front of the barrier.  With A first
     // the youngest operations ahead of the wait are last round's stores -- long done -- and this round's stores have until
     // the next round's A.
+    unsigned long long a_span = 0;   // diagnostic build: cycles of this round's A stage (it runs inside the D section for waves 0-7)
     auto run_a = [&]() {
+      const unsigned long long a_t0 = PROF ? __builtin_amdgcn_s_memtime() : 0;
       int a_smp = 0, a_s = -1, a_sg = 0, a_sl = 0;
       if (r < G) strip_of(r, a_smp, a_s, a_sg, a_sl);
       if (hasA && r < G && !TAIL_ABL(4)) {
@@ -492,6 +494,7 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
         }
         }
       }
+      if (PROF) a_span = __builtin_amdgcn_s_memtime() - a_t0;
     };
     // ---------------- BC: ConvT#3 + ConvT#4 on 32 pixels of the 100-level ----------------
     auto do_bc = [&]() {
@@ -724,7 +727,8 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
     lds_barrier();
     if (PROF) {
       ts[5] = __builtin_amdgcn_s_memtime();
-      tD += (ts[1] - ts[0]) + (ts[3] - ts[2]); tBC += ts[2] - ts[1]; tA += ts[4] - ts[3]; tBar += ts[5] - ts[4];
+      const bool a_in_d = !(TAIL_ABL(16) ? false : (TAIL_ABL(32) ? true : wave >= 8));   // A ran between BC and D (inside ts[2]..ts[3])
+      tD += (ts[1] - ts[0]) + (ts[3] - ts[2]) - (a_in_d ? a_span : 0); tBC += ts[2] - ts[1]; tA += a_span; tBar += ts[5] - ts[4];
     }
   }
   if (PROF && p.prof && blockIdx.x == 0 && lane == 0) {
