@@ -1,7 +1,8 @@
 // Host side of the bf16 / f16 throughput path for the encoder_10 + decoder_400
 // graph: weight repacking (16-bit, log2e folding, MFMA fragment order) and the
-// eight-launch pipeline  conv1 -> conv2 -> dense -> latent -> dense_1 ->
-// ConvT#0 (4 phases) -> ConvT#1 -> fused tail.
+// four-launch pipeline  enc16 (conv2d .. latent_vector) -> dense1_16 -> mid16
+// (ConvT#0 -> ConvT#1) -> tail16; the layer-by-layer launches they replaced
+// stay reachable (SRCFD_ENC=0, SRCFD_DENSE1=0, SRCFD_MID=0) for the A/B tests.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
