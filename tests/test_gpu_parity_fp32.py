@@ -79,6 +79,32 @@ def test_one_launch_f32_encoder_against_the_layer_by_layer_launches(srcfd, oracl
     np.testing.assert_array_equal(enc.predict(x, in_affine=ain), enc.predict(xn))
 
 
+@pytest.mark.parametrize("precision,tol", [("fp32", TOL_FP32), ("bf16", 2e-2)])
+def test_one_launch_encoders_on_random_weights(srcfd, oracle, precision, tol):
+    """The fragment packing of enc32 / enc16 / dense_skinny32 / dense1_16 on weights that are not the trained ones: Keras'
+    default initialisation of both sub-models, two seeds (a packing error that happens to be small on the trained encoder
+    would not be small here).  bf16 is additionally held to 5e-3 of its CPU emulation (measured 6e-4).  f16 is not part of
+    this test: with default-initialised weights the activations of this network fall into f16's denormal range and the
+    FORMAT loses 1.6e-2 (the emulation itself is that far from float64; all kernel variants agree with each other)."""
+    import importlib
+    require_gpu(srcfd)
+    synth = importlib.import_module("sr-for-cfd_amd.synth")
+    rng = np.random.default_rng(17)
+    x = rng.standard_normal((7, 10, 10, 1)).astype(np.float32)
+    for seed in (3, 4):
+        enc, dec = synth.keras_default_init(seed)
+        m = srcfd.SRModel.from_weights(enc, dec, device=0)
+        m.precision = precision
+        y = m.predict(x)
+        ref = oracle.superres_forward(x, enc, dec, np.float64)
+        err = oracle.rel_l2(y, ref)
+        print(f"{precision} seed {seed}: rel L2 {err:.2e}")
+        assert err <= tol
+        if precision == "bf16":
+            from oracle import sr_oracle_lowp as lp
+            assert oracle.rel_l2(y, lp.superres_forward_lowp(x, enc, dec, "bf16")) <= 5e-3
+
+
 LAYER_CASES = [
     # name, spec builder args: kind, k, stride, same, cin, cout, in_hw
     ("conv_same_s2_asym_pad", "conv2d", 3, 2, True, 1, 64, (10, 10)),
