@@ -44,7 +44,7 @@ struct TailParams {
   int nan_guard;
   unsigned long long* nonfinite;
   int out_dtype;
-  int ablate;              // diagnostic (SRCFD_TAIL_ABLATE): 1 no swish, 2 no D, 4 no A, 8 no BC, 16 BC before D, 32 D before BC, 128 no priority raise
+  int ablate;              // diagnostic (SRCFD_TAIL_ABLATE): 1 no swish, 2 no D, 4 no A, 8 no BC, 16 BC before D, 32 D before BC, 64 skip the D items that hold only tiles 48-49 of a row pair, 128 no priority raise
   int seg;                 // segments per sample (1, 2, 5, 10 or 25): small batches spread one sample over several workgroups
   unsigned long long* prof;  // diagnostic (SRCFD_TAIL_PROF): per-wave cycle totals [block 0][16 waves][D, BC, A, barrier, total], else null
 };

@@ -560,6 +560,7 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
       // fast path: row pair rp of strip gd, all four window rows inside one sample
       auto d_fast = [&](const int it, const int rowoff0, const int rowoff1) {
         const int item = d_first + it, rp = item >> 2, j4 = item & 3;
+        if (TAIL_ABL(64) && j4 == 3) return;   // diagnostic: what the 2-of-16-tile items at the end of every row pair cost
         f32x4 acc = {conv_bias, conv_bias, conv_bias, conv_bias};
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
