@@ -79,6 +79,57 @@ __device__ __forceinline__ void swish_pack16(const f32x16& dd, uint32_t (&o)[8],
   for (int i = 0; i < 8; ++i) o[i] = pack2<F16>(e2[i].x, e2[i].y);
 }
 
+// The same swish + pack over NR (8 or 16) accumulator registers starting at R0, with four places where the caller may put
+// instructions of ANOTHER dependency chain -- MFMAs of the next stage -- into this wave's own instruction stream: after the first
+// and the second half of the exps, and after the first and the second half of the rcps.  Round 3 (tools/microbench9.hip,
+// profiles/r03): a v_mfma_f32_32x32x16_bf16 issued between the transcendentals of the same wave costs 3.6 ns of SIMD time against
+// 10.7 ns when it is issued in front of the block and waited for -- the matrix pipe runs under the wave's own vector stream, which
+// it does not do under another wave's (profiles/r02/d_...).  A hook is `[&] { pin(); acc = mfma32(...); pin(); }` with
+// pin() = __builtin_amdgcn_sched_barrier(0): hipcc may otherwise move the builtin MFMA anywhere its operands allow.  The MFMA stays a
+// builtin so that hipcc pads its hazards (VALU write -> MFMA operand, MFMA result -> VALU read) itself.
+struct no_hook { __device__ __forceinline__ void operator()() const {} };
+__device__ __forceinline__ void pin() { __builtin_amdgcn_sched_barrier(0); }
+
+template <bool F16, int R0, int NR, class H0 = no_hook, class H1 = no_hook, class H2 = no_hook, class H3 = no_hook>
+__device__ __forceinline__ void swish_pack_h(const f32x16& dd, uint32_t* o, H0&& h0 = no_hook(), H1&& h1 = no_hook(), H2&& h2 = no_hook(),
+                                             H3&& h3 = no_hook()) {
+  constexpr int NP = NR / 2;
+  f32x2 u2[NP], e2[NP];
+  const f32x2 one2 = {1.0f, 1.0f};
+#pragma unroll
+  for (int i = 0; i < NP; ++i) u2[i] = f32x2{dd[R0 + 2 * i], dd[R0 + 2 * i + 1]};
+#pragma unroll
+  for (int i = 0; i < NP / 2; ++i) {
+    e2[i].x = __builtin_amdgcn_exp2f(-u2[i].x);
+    e2[i].y = __builtin_amdgcn_exp2f(-u2[i].y);
+  }
+  h0();
+#pragma unroll
+  for (int i = NP / 2; i < NP; ++i) {
+    e2[i].x = __builtin_amdgcn_exp2f(-u2[i].x);
+    e2[i].y = __builtin_amdgcn_exp2f(-u2[i].y);
+  }
+  h1();
+#pragma unroll
+  for (int i = 0; i < NP; ++i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(e2[i]) : "v"(one2));
+#pragma unroll
+  for (int i = 0; i < NP / 2; ++i) {
+    asm volatile("v_rcp_f32 %0, %0" : "+v"(e2[i].x));
+    asm volatile("v_rcp_f32 %0, %0" : "+v"(e2[i].y));
+  }
+  h2();
+#pragma unroll
+  for (int i = NP / 2; i < NP; ++i) {
+    asm volatile("v_rcp_f32 %0, %0" : "+v"(e2[i].x));
+    asm volatile("v_rcp_f32 %0, %0" : "+v"(e2[i].y));
+  }
+  h3();
+#pragma unroll
+  for (int i = 0; i < NP; ++i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(e2[i]) : "v"(u2[i]));
+#pragma unroll
+  for (int i = 0; i < NP; ++i) o[i] = pack2<F16>(e2[i].x, e2[i].y);
+}
+
 __device__ __forceinline__ f32x16 load_bias16(const char* base) {
   f32x16 r;
   const float4* p = reinterpret_cast<const float4*>(base);

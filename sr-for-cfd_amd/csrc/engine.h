@@ -31,6 +31,33 @@ struct ProfEvent {
 
 struct FusedState;  // bf16/f16 path (fused_bf16.hip)
 
+// Functional A/B switches: every one selects a COMPLETE alternative implementation of a stage (no work is skipped), for the parity
+// tests and the tools.  They are read from the environment once per srcfd_predict* call (Switches::from_env), are part of the hipGraph
+// key (a captured forward is replayed only under the switches it was captured with) and are reported by srcfd_model_last_plan.
+struct Switches {
+  bool enc16 = true;     // SRCFD_ENC=0: layer-by-layer 16-bit encoder instead of the one-launch enc16
+  bool mid16 = true;     // SRCFD_MID=0: generic GEMMs instead of the fused ConvT#0 -> ConvT#1 kernel
+  bool dense1_16 = true; // SRCFD_DENSE1=0: dense_1 on the generic 16-bit GEMM
+  bool enc32 = true;     // SRCFD_NO_ENC32=1: layer-by-layer f32 encoder
+  bool skinny32 = true;  // SRCFD_NO_DENSE_SKINNY=1: dense_1 on the generic f32 GEMM
+  int tail_seg = 0;      // SRCFD_TAIL_SEG: segments per sample of the 16-bit tail (1, 2, 5, 10, 25); 0 = chosen per batch
+  unsigned bits() const {
+    return (enc16 ? 1u : 0u) | (mid16 ? 2u : 0u) | (dense1_16 ? 4u : 0u) | (enc32 ? 8u : 0u) | (skinny32 ? 16u : 0u) | ((unsigned)tail_seg << 8);
+  }
+  bool all_default() const { return enc16 && mid16 && dense1_16 && enc32 && skinny32 && tail_seg == 0; }
+  static Switches from_env();
+};
+
+// What the last forward of a handle ran (srcfd_model_last_plan): the switches it saw, the tail segmentation that was launched and how
+// the launches were issued.
+struct Plan {
+  Switches sw;
+  int precision = 0;
+  int tail_seg = 0;   // 16-bit tail: segments per sample actually launched (last chunk)
+  int graph = 0;      // 0 plain launches, 1 captured now and launched as a graph, 2 replay of an earlier capture
+  bool fused = false;
+};
+
 struct Model {
   ModelDesc desc;
   int device = -1;
@@ -80,12 +107,15 @@ struct Model {
   struct GraphKey {
     const void* x = nullptr; const void* y = nullptr; const float* ain = nullptr; const float* aout = nullptr;
     unsigned long long* nf = nullptr; int n = -1, out_dtype = 0, flags = 0, precision = 0;
+    unsigned switches = 0;   // Switches::bits(): the A/B switches select different kernels, so they belong to the key
     bool operator==(const GraphKey& o) const {
       return x == o.x && y == o.y && ain == o.ain && aout == o.aout && nf == o.nf && n == o.n && out_dtype == o.out_dtype &&
-             flags == o.flags && precision == o.precision;
+             flags == o.flags && precision == o.precision && switches == o.switches;
     }
   };
   GraphKey graph_key, last_key;
+  Switches sw;            // of the call in progress
+  Plan plan, graph_plan;  // of the last forward / of the captured graph
   hipGraphExec_t graph_exec = nullptr;
   hipStream_t graph_stream = nullptr;
   void drop_graph();

@@ -295,6 +295,20 @@ Model::~Model() {
   }
 }
 
+Switches Switches::from_env() {
+  auto on = [](const char* name, bool dflt) { const char* e = getenv(name); return e ? atoi(e) != 0 : dflt; };
+  Switches w;
+  w.enc16 = on("SRCFD_ENC", true);
+  w.mid16 = on("SRCFD_MID", true);
+  w.dense1_16 = on("SRCFD_DENSE1", true);
+  w.enc32 = !on("SRCFD_NO_ENC32", false);
+  w.skinny32 = !on("SRCFD_NO_DENSE_SKINNY", false);
+  const char* e = getenv("SRCFD_TAIL_SEG");
+  const int seg = e ? atoi(e) : 0;
+  w.tail_seg = (seg == 1 || seg == 2 || seg == 5 || seg == 10 || seg == 25) ? seg : 0;
+  return w;
+}
+
 void Model::drop_graph() {
   if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
   graph_key = GraphKey();
@@ -408,7 +422,7 @@ int Model::forward_generic(const float* x_dev, int n, const float* aff_in, const
   int rc = SRCFD_OK;
   int prev_layer = -1;
   size_t first = 0;
-  const bool no_enc32 = [] { const char* e = getenv("SRCFD_NO_ENC32"); return e && atoi(e) != 0; }();   // functional A/B switch of the tests: read per call
+  const bool no_enc32 = !sw.enc32;   // functional A/B switch of the tests (Switches, engine.h)
   if (enc32_ok && !naive && !no_enc32) {   // standardise + the encoder's four layers: one launch, latent vectors into buf[0]
     Enc32Params ep;
     ep.x = x_dev; ep.affine = aff_in; ep.n = n;
@@ -501,7 +515,7 @@ int Model::forward_generic(const float* x_dev, int n, const float* aff_in, const
       continue;
     }
     static const bool no_big1 = [] { const char* e = getenv("SRCFD_NO_GEMM32_BIG"); return e && atoi(e) != 0; }();
-    const bool no_skinny = [] { const char* e = getenv("SRCFD_NO_DENSE_SKINNY"); return e && atoi(e) != 0; }();   // (read per call, as above)
+    const bool no_skinny = !sw.skinny32;
     if (!naive && !no_skinny && dense_skinny32_qualifies(d)) {
       rc = launch(op.name.c_str(), s, [&] { return launch_dense_skinny32(d, X, B, bias, Y, s); });
       if (rc) return rc;
@@ -529,7 +543,10 @@ int Model::predict_device(const void* x_dev, int n, const float* aff_in, const f
   if (n == 0) return SRCFD_OK;
   HIPCHECK(hipSetDevice(device));
   prof_used = 0;
+  sw = Switches::from_env();
   const bool use_fused = (precision == SRCFD_PREC_BF16 || precision == SRCFD_PREC_F16);
+  plan = Plan();
+  plan.sw = sw; plan.precision = precision; plan.fused = use_fused;
   if (use_fused && !has_fused) { set_error("bf16/f16 precision needs the encoder_10+decoder_400 layer graph; use SRCFD_PREC_FP32 for other graphs"); return SRCFD_EINVAL; }
   if (!use_fused) {
     int rc = ensure_workspace(n);  // (re)allocates before anything is captured; drops a stale graph when it does
@@ -559,9 +576,10 @@ int Model::predict_device(const void* x_dev, int n, const float* aff_in, const f
   if (graphs) {
     GraphKey key;
     key.x = x_dev; key.y = y_dev; key.ain = aff_in; key.aout = aff_out; key.nf = nonfinite; key.n = n;
-    key.out_dtype = out_dtype; key.flags = flags; key.precision = precision;
+    key.out_dtype = out_dtype; key.flags = flags; key.precision = precision; key.switches = sw.bits();
     if (graph_exec && key == graph_key) {
       HIPCHECK(hipGraphLaunch(graph_exec, s));
+      plan = graph_plan; plan.graph = 2;
       return SRCFD_OK;
     }
     if (key == last_key && !(key == graph_key)) {
@@ -577,7 +595,9 @@ int Model::predict_device(const void* x_dev, int n, const float* aff_in, const f
         (void)hipGraphDestroy(g);
         if (e == hipSuccess) {
           graph_key = key;
+          graph_plan = plan;
           HIPCHECK(hipGraphLaunch(graph_exec, s));
+          plan.graph = 1;
           return SRCFD_OK;
         }
         graph_exec = nullptr;
@@ -867,6 +887,22 @@ int srcfd_model_get_profile(srcfd_model* m, char* names, size_t names_len, float
   }
   *count = n;
   if (names && names_len) std::snprintf(names, names_len, "%s", joined.c_str());
+  return SRCFD_OK;
+}
+
+int srcfd_model_last_plan(const srcfd_model* m, char* buf, size_t buf_len) {
+  if (!m || !buf || buf_len == 0) { set_error("bad arguments"); return SRCFD_EINVAL; }
+  const srcfd::Plan& p = M(m)->plan;
+  const char* prec = p.precision == SRCFD_PREC_BF16 ? "bf16" : p.precision == SRCFD_PREC_F16 ? "f16" : p.precision == SRCFD_PREC_FP32 ? "fp32" : "fp32_naive";
+  char tmp[256];
+  if (p.fused)
+    snprintf(tmp, sizeof(tmp), "precision=%s encoder=%s dense_1=%s middle=%s tail_seg=%d graph=%s", prec, p.sw.enc16 ? "enc16" : "layers",
+             p.sw.dense1_16 ? "dense1_16" : "gemm16", p.sw.mid16 ? "mid16" : "gemm16", p.tail_seg,
+             p.graph == 2 ? "replay" : p.graph == 1 ? "capture" : "eager");
+  else
+    snprintf(tmp, sizeof(tmp), "precision=%s encoder=%s dense_1=%s graph=%s", prec, p.sw.enc32 ? "enc32" : "layers",
+             p.sw.skinny32 ? "dense_skinny32" : "gemm32", p.graph == 2 ? "replay" : p.graph == 1 ? "capture" : "eager");
+  snprintf(buf, buf_len, "%s", tmp);
   return SRCFD_OK;
 }
 

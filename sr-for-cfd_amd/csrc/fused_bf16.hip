@@ -361,10 +361,11 @@ int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, cons
     const float* ain = aff_in ? aff_in + 2 * (size_t)i0 : nullptr;
     const float* aout = aff_out ? aff_out + 2 * (size_t)i0 : nullptr;
     int cur = 0;
-    // functional A/B switches of the tests (both implementations of the encoder and of the network's middle are complete): read per call
-    const bool use_enc = fs->enc_ok && [] { const char* e = getenv("SRCFD_ENC"); return !e || atoi(e) != 0; }();  // 0: layer-by-layer encoder
-    const bool use_mid = [] { const char* e = getenv("SRCFD_MID"); return !e || atoi(e) != 0; }();  // 0: generic GEMMs (A/B, tests)
-    const bool use_d1 = [] { const char* e = getenv("SRCFD_DENSE1"); return !e || atoi(e) != 0; }();  // 0: dense_1 on the generic GEMM
+    // functional A/B switches of the tests (both implementations of the encoder, of dense_1 and of the network's middle are complete):
+    // read once per call by Model::predict_device (Switches, engine.h), part of the hipGraph key
+    const bool use_enc = fs->enc_ok && m.sw.enc16;   // false: layer-by-layer encoder
+    const bool use_mid = m.sw.mid16;                 // false: generic GEMMs
+    const bool use_d1 = m.sw.dense1_16;              // false: dense_1 on the generic GEMM
     if (use_enc) {
       EncParams ep;
       ep.x = xin; ep.affine = ain; ep.n = c;
@@ -469,17 +470,17 @@ int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, cons
     // sample into S segments so that the longest workgroup walks fewer strips.  Cost of a choice = strips walked by the
     // busiest workgroup: ceil(n S / CUs) virtual samples of 50/S (+1 warm-up) strips, + 2 rounds of pipeline depth.
     int seg = 1;
-    { static const int seg_env = [] { const char* e = getenv("SRCFD_TAIL_SEG"); return e ? atoi(e) : 0; }();  // read once
-      if (seg_env) seg = seg_env;
-      else {
-        long best = ((long)(c + fs->num_cus - 1) / fs->num_cus) * 50 + 2;
-        for (int cand : {2, 5, 10, 25}) {
-          long cost = ((long)((long)c * cand + fs->num_cus - 1) / fs->num_cus) * (50 / cand + 1) + 2;
-          if (cost * 115 < best * 100) { best = cost; seg = cand; }  // warm-up strips and extra workgroups are not free: ask for 15 %
-        }
-      } }
+    if (m.sw.tail_seg) seg = m.sw.tail_seg;   // SRCFD_TAIL_SEG (tests, tools): read per call, reported by srcfd_model_last_plan
+    else {
+      long best = ((long)(c + fs->num_cus - 1) / fs->num_cus) * 50 + 2;
+      for (int cand : {2, 5, 10, 25}) {
+        long cost = ((long)((long)c * cand + fs->num_cus - 1) / fs->num_cus) * (50 / cand + 1) + 2;
+        if (cost * 115 < best * 100) { best = cost; seg = cand; }  // warm-up strips and extra workgroups are not free: ask for 15 %
+      }
+    }
     if (seg != 1 && seg != 2 && seg != 5 && seg != 10 && seg != 25) seg = 1;
     tp.seg = seg;
+    m.plan.tail_seg = seg;
     const int blocks = std::min(c * seg, fs->num_cus);
     rc = m.launch("tail(convT2-4+out)", s, [&] { return launch_tail16(f16, tp, blocks, s); });
     if (rc) return rc;

@@ -365,8 +365,9 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
   // vector instructions -- on this chip vector and matrix instructions of a SIMD do not overlap, so they are kernel time.)
   constexpr int OUTSZ = OUT == 0 ? 4 : 2;
   const int d_rowlane = d_dy * T_ROWP;                               // window row of this lane's k-group, relative to the item's first
-  const int d_olane = (((lane >> 3) & 1) * 400 + 8 * (lane >> 4) + (lane & 7)) * OUTSZ;   // output byte offset inside the item's row pair
-  const int d_kg = lane >> 4;
+  // fast path (operands swapped, below): lane (n = lane & 15, kg = lane >> 4) stores pixels 4 (kg & 1) .. + 3 of row kg >> 1 of tile d_tsel
+  const int d_olane = ((lane >> 5) * 400 + 8 * d_tsel + 4 * ((lane >> 4) & 1)) * OUTSZ;   // output byte offset inside the item's row pair
+  const bool d_last_on = d_tsel < 2;                                                       // tiles 48, 49: the two that exist in a row pair's fourth item
 
   // ---- static schedule (per round: 14 BC, 8 A, 16 D items over 16 waves) ----
   // The kernel is VALU-issue bound and wave w runs on SIMD w % 4, so the schedule balances VALU instructions
@@ -575,41 +576,38 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
           av[3] = *reinterpret_cast<const uint4*>(p1 + 4 * T_PLANE * 16);
 #pragma unroll
           for (int cp = 0; cp < 5; ++cp) wv[cp] = wc_f[(half * 5 + cp) * 64 + lane];
+          // Operands SWAPPED against the seam path (round 3): the Toeplitz weights are the A operand (rows = the tile's 16 pixels),
+          // the window activations the B operand (columns = the item's 16 tiles).  Both operands keep their per-lane registers
+          // (lane & 15 indexes the non-k dimension of either), only the accumulator is transposed: register rr of lane group kg
+          // is now pixel 4 kg + rr of tile (lane & 15) -- four CONSECUTIVE pixels of one output row, one 16-byte store per lane
+          // instead of four 4-byte stores 32 pixels apart.  Same products, same k order per output: bit-identical to the seam path.
 #pragma unroll
-          for (int cp = 0; cp < 5; ++cp) acc = mfma16<F16>(av[cp], wv[cp], acc);
+          for (int cp = 0; cp < 5; ++cp) acc = mfma16<F16>(wv[cp], av[cp], acc);
           __builtin_amdgcn_sched_barrier(0);
         }
-        // accumulator register rr of lane group kg holds tile 16*j4 + 4rr + kg, pixel (oy, ox) = lane & 15: the row pair's
-        // base is wave-uniform, the lane adds a constant, rr an immediate
+        // lane (n = lane & 15, kg): tile 16 j4 + d_tsel(n), output row oy = kg >> 1 of the pair, pixels 4 (kg & 1) .. + 3 of the tile
         char* orow = reinterpret_cast<char*>(p.out) + (((size_t)sample_d * 400 + (8 * s_d - 1 + 2 * rp)) * 400 + 128 * j4) * OUTSZ;
-        float v[4] = {acc[0], acc[1], acc[2], acc[3]};
-        if (p.aff_out) {
+        float v[4];
+        // de-standardise with ONE fma per value on this 16-bit path (the f32 parity path keeps numpy's two roundings, kernels_tail32.hip):
+        // <= 1 ulp from y * std + mean, four instructions instead of two packed multiplies + two packed adds + four selects
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) v[rr] = __fadd_rn(__fmul_rn(v[rr], o_std), o_mean);
+        for (int rr = 0; rr < 4; ++rr) v[rr] = __builtin_fmaf(acc[rr], o_std, o_mean);   // without aff_out: std = 1, mean = 0 -> v exactly
+        const bool lane_on = j4 < 3 || d_last_on;   // item 3 of a row pair holds tiles 48, 49 only
+        if (p.nan_guard) {
+          unsigned nbad = 0;
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const bool ok = fabsf(v[rr]) <= 3.402823466e38f;
+            nbad += (unsigned)__popcll(__ballot(!ok && lane_on));
+            v[rr] = ok ? v[rr] : 0.f;
+          }
+          bad_wave += nbad;
         }
-        auto st = [&](const int rr) {
-          char* o = orow + d_olane + 32 * rr * OUTSZ;
-          if (OUT == 0) *reinterpret_cast<float*>(o) = v[rr];
-          else if (OUT == 1) *reinterpret_cast<uint16_t*>(o) = (uint16_t)(pack2<false>(v[rr], 0.f) & 0xffff);
-          else *reinterpret_cast<uint16_t*>(o) = (uint16_t)(pack2<true>(v[rr], 0.f) & 0xffff);
-        };
-        if (j4 < 3) {
-          if (p.nan_guard) {
-#pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-              const bool bad = !(fabsf(v[rr]) <= 3.402823466e38f);
-              bad_wave += (unsigned)__popcll(__ballot(bad));
-              v[rr] = bad ? 0.f : v[rr];
-            }
-          }
-          st(0); st(1); st(2); st(3);
-        } else if (d_kg < 2) {          // tiles 48, 49 of the row pair; the other 14 of this item do not exist
-          if (p.nan_guard) {
-            const bool bad = !(fabsf(v[0]) <= 3.402823466e38f);
-            bad_wave += (unsigned)__popcll(__ballot(bad));
-            v[0] = bad ? 0.f : v[0];
-          }
-          st(0);
+        if (lane_on) {
+          char* o = orow + d_olane;
+          if (OUT == 0) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+          else if (OUT == 1) *reinterpret_cast<uint2*>(o) = make_uint2(pack2<false>(v[0], v[1]), pack2<false>(v[2], v[3]));
+          else *reinterpret_cast<uint2*>(o) = make_uint2(pack2<true>(v[0], v[1]), pack2<true>(v[2], v[3]));
         }
       };
       auto do_d = [&](const int item) {  // seam rows (sample / segment boundaries): called (not looped) so no conservative vmcnt(0) lands in front of it
@@ -659,7 +657,7 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
           for (int rr = 0; rr < 4; ++rr) {
             if (txo + 4 * rr >= 50) continue;
             float v = acc[rr];
-            if (p.aff_out) v = __fadd_rn(__fmul_rn(v, sdv), mean);
+            if (p.aff_out) v = __builtin_fmaf(v, sdv, mean);   // one fma, as the fast path: every row of an image goes through the same arithmetic whatever the segmentation
             if (p.nan_guard && !(fabsf(v) <= 3.402823466e38f)) { v = 0.f; ++bad_count; }
             const size_t o = o0 + 32 * rr;
             if (OUT == 0) reinterpret_cast<float*>(p.out)[o] = v;

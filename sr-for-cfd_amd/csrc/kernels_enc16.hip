@@ -321,6 +321,12 @@ __global__ void __launch_bounds__(64 * D1_WAVES, 1) dense1_16(const uint16_t* __
       const uint2 o = make_uint2(pack2<F16>(act16(acc[0], act), act16(acc[1], act)), pack2<F16>(act16(acc[2], act), act16(acc[3], act)));
       *reinterpret_cast<uint2*>(st + col * D1_PITCH + ft * 32 + kg * 8) = o;
     }
+    // the tile is wave-private: lanes read chunks other lanes of the SAME wave wrote.  The hardware executes one wave's LDS
+    // operations in order; the wave-scope fence + barrier keep the compiler from moving these loads above the stores (and, below,
+    // the next tile's stores above these loads) -- no instruction is emitted for either
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // write-out: 16 samples x 18 chunks of 16 B, consecutive lanes on consecutive chunks of one sample's 288-byte run
 #pragma unroll
     for (int r = 0; r < (16 * D1_NF / 8 + 63) / 64; ++r) {
@@ -330,6 +336,9 @@ __global__ void __launch_bounds__(64 * D1_WAVES, 1) dense1_16(const uint16_t* __
         *reinterpret_cast<uint4*>(Y + (size_t)s * N + n0 + ch * 8) = v;
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     xb[0] = xn[0]; xb[1] = xn[1];
   }
 }

@@ -268,12 +268,21 @@ __global__ void __launch_bounds__(64 * DS_WAVES, 1) dense_skinny32(GemmDesc d, c
       }
       *reinterpret_cast<f32x4*>(st + col * DS_PITCH + ft * 64 + kg * 16) = acc;
     }
+    // the tile is wave-private: lanes read chunks other lanes of the SAME wave wrote.  The hardware executes one wave's LDS
+    // operations in order; the wave-scope fence + barrier keep the compiler from moving these loads above the stores (and, below,
+    // the next tile's stores above these loads) -- no instruction is emitted for either
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     // write-out: 16 samples x 36 chunks of 16 B, consecutive lanes on consecutive chunks of one sample's 576-byte run
 #pragma unroll
     for (int r = 0; r < 16 * DS_NF / 4 / 64; ++r) {
       const int c = lane + 64 * r, row = c / (DS_NF / 4), ch = c - row * (DS_NF / 4), s = t * 16 + row;
       if (s < M) *reinterpret_cast<f32x4*>(Y + (size_t)s * N + n0 + ch * 4) = *reinterpret_cast<const f32x4*>(st + row * DS_PITCH + ch * 16);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
 }
 

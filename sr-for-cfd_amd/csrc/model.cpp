@@ -487,27 +487,47 @@ static std::string reference_submodel_config(const std::string& name, h5lite::No
     o << "{\"class_name\": \"Dense\", \"config\": {\"name\": \"" << ln << "\", \"units\": " << kd[1] << ", \"activation\": \"" << act << "\"}}";
     return o.str();
   };
+  // Layer-group NAMES say nothing about strides and padding, and the notebook's other variants (Conv2DTranspose(.., 3, strides=2,
+  // padding='same'), encoders with several stride-2 convolutions) use the same names: the fallback accepts a file only when its
+  // kernel shapes are exactly encoder_lr's / decoder_hr's (3x3 s2 + 3x3 s1 convolutions; transposed kernels 3,2,2,2,2 with
+  // 'valid' padding; 3x3 output convolution; dense widths consistent with a square feature map), otherwise it refuses.
+  auto expect = [&](bool ok, const std::string& what) {
+    if (!ok) throw std::runtime_error("whole-model file without sub-model configs: architecture not recoverable from this file (" + name + ": " + what +
+                                      " differs from the reference encoder_lr / decoder_hr)");
+  };
+  auto ksize = [&](const std::string& ln, uint64_t k) {
+    auto kd = shape_of(ln, "kernel");
+    expect(kd.size() == 4 && kd[0] == k && kd[1] == k, ln + " kernel size");
+  };
   std::ostringstream o;
   o << "{\"name\": \"" << name << "\", \"layers\": [";
   if (g->child("conv2d") && g->child("latent_vector")) {   // encoder_lr (sr-ae-conv.ipynb:c162-169)
+    ksize("conv2d", 3); ksize("conv2d_1", 3);
+    expect(!g->child("conv2d_2"), "number of convolutions");
     const uint64_t lat_in = shape_of("dense", "kernel")[0], c2 = shape_of("conv2d_1", "kernel")[3];
     const int side2 = (int)std::lround(std::sqrt((double)lat_in / (double)c2));   // conv output side: stride-2 SAME of the input
+    expect((uint64_t)side2 * side2 * c2 == lat_in, "dense input width");
+    expect(shape_of("conv2d_1", "kernel")[2] == shape_of("conv2d", "kernel")[3], "conv2d_1 input channels");
+    expect(shape_of("latent_vector", "kernel")[0] == shape_of("dense", "kernel")[1], "latent_vector input width");
     o << "{\"class_name\": \"InputLayer\", \"config\": {\"name\": \"" << name << "_input\", \"batch_shape\": [null, " << 2 * side2 << ", " << 2 * side2 << ", "
       << shape_of("conv2d", "kernel")[2] << "]}}, " << conv("conv2d", "Conv2D", 2, "same", "swish") << ", " << conv("conv2d_1", "Conv2D", 1, "same", "swish")
       << ", {\"class_name\": \"Flatten\", \"config\": {\"name\": \"flatten\"}}, " << dense("dense", "swish") << ", " << dense("latent_vector", "linear");
   } else if (g->child("dense_1") && g->child("conv2d_transpose")) {   // decoder_hr (sr-ae-conv.ipynb:c277-287)
     const uint64_t units = shape_of("dense_1", "kernel")[1], cin = shape_of("conv2d_transpose", "kernel")[3];
     const int side = (int)std::lround(std::sqrt((double)units / (double)cin));
+    expect((uint64_t)side * side * cin == units, "dense_1 units");
     o << "{\"class_name\": \"InputLayer\", \"config\": {\"name\": \"" << name << "_input\", \"batch_shape\": [null, " << shape_of("dense_1", "kernel")[0] << "]}}, "
       << dense("dense_1", "swish") << ", {\"class_name\": \"Reshape\", \"config\": {\"name\": \"reshape\", \"target_shape\": [" << side << ", " << side << ", " << cin << "]}}";
     for (int i = 0;; ++i) {
       const std::string ln = i == 0 ? "conv2d_transpose" : "conv2d_transpose_" + std::to_string(i);
-      if (!g->child(ln)) break;
+      if (!g->child(ln)) { expect(i == 5, "number of transposed convolutions"); break; }
+      ksize(ln, i == 0 ? 3 : 2);
       o << ", " << conv(ln, "Conv2DTranspose", 2, "valid", "swish");
     }
     std::string outl;
     for (auto& c : g->children) if (c.first.rfind("output_image", 0) == 0) outl = c.first;
     if (outl.empty()) throw std::runtime_error("whole-model file: no output_image_* layer");
+    ksize(outl, 3);
     o << ", " << conv(outl, "Conv2D", 1, "same", "linear");
   } else throw std::runtime_error("whole-model file: sub-model '" + name + "' is neither the reference encoder nor decoder");
   o << "]}";

@@ -232,7 +232,7 @@ namespace srcfd {
 // eight-accumulator block for n <= 128, float32 division and sqrt, and NumPy-2 scalar promotion of the blend (a Python
 // float next to a float32 scalar is rounded to float32 first) -- so that the (mean, std) pair equals the host recipe's.
 // ---------------------------------------------------------------------------
-__device__ float np_pairwise_sum_f32(const float* a, int n) {   // numpy/_core/src/umath/loops_utils.h.src, pairwise_sum, n <= 128
+__device__ float np_pairwise_block_f32(const float* a, int n) {   // numpy/_core/src/umath/loops_utils.h.src, pairwise_sum: the n <= 128 block
   if (n < 8) {
     float res = 0.f;
     for (int i = 0; i < n; ++i) res = __fadd_rn(res, a[i]);
@@ -247,6 +247,18 @@ __device__ float np_pairwise_sum_f32(const float* a, int n) {   // numpy/_core/s
   for (; i < n; ++i) res = __fadd_rn(res, a[i]);
   return res;
 }
+// ... and its recursion above 128 elements (n2 = n / 2, rounded down to a multiple of 8; left sum + right sum): sides up to
+// PREP_MAX = 32 give n <= 1024 = 128 * 8, three levels
+template <int DEPTH>
+__device__ float np_pairwise_sum_f32_rec(const float* a, int n) {
+  if (n <= 128) return np_pairwise_block_f32(a, n);
+  int n2 = n / 2;
+  n2 -= n2 % 8;
+  return __fadd_rn(np_pairwise_sum_f32_rec<DEPTH - 1>(a, n2), np_pairwise_sum_f32_rec<DEPTH - 1>(a + n2, n - n2));
+}
+template <>
+__device__ float np_pairwise_sum_f32_rec<0>(const float* a, int n) { return np_pairwise_block_f32(a, n); }
+__device__ float np_pairwise_sum_f32(const float* a, int n) { return np_pairwise_sum_f32_rec<4>(a, n); }   // n <= 2048
 
 constexpr int PREP_MAX = 32;   // source and target sides up to 32 (the path's coarse fields are 10 x 10)
 

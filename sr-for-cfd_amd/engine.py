@@ -334,6 +334,13 @@ class SRModel:
         L.check(L.lib.srcfd_model_debug_activation(self._h, index, out.ctypes.data_as(C.c_void_p), out.nbytes))
         return out
 
+    def last_plan(self) -> dict:
+        """Test hook (srcfd_model_last_plan): which implementation of each stage the last forward ran, e.g.
+        {'precision': 'bf16', 'encoder': 'enc16', 'dense_1': 'dense1_16', 'middle': 'mid16', 'tail_seg': '10', 'graph': 'eager'}."""
+        buf = C.create_string_buffer(512)
+        L.check(L.lib.srcfd_model_last_plan(self._h, buf, len(buf)))
+        return dict(w.split("=", 1) for w in buf.value.decode().split())
+
     def set_profiling(self, on: bool):
         L.check(L.lib.srcfd_model_set_profiling(self._h, int(on)))
 

@@ -313,6 +313,39 @@ def test_batched_call_prepares_its_inputs_on_the_device(srcfd, decoder_h5, coars
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("side", [11, 12, 16, 23, 32])
+def test_device_statistics_follow_numpy_beyond_128_elements(srcfd, side):
+    """include/srcfd.h promises numpy's float32 mean / std bit for bit for sides up to 32: above 128 elements numpy's
+    pairwise sum recurses (n/2 rounded down to a multiple of 8); 11x11 = 121 is the last one-block size, 12x12 the first split."""
+    import ctypes as C
+    import torch
+    require_gpu(srcfd)
+    L = importlib.import_module("sr-for-cfd_amd._lib")
+    rng = np.random.default_rng(side)
+    n = 6
+    fields = (rng.standard_normal((n, side, side)) * rng.uniform(0.1, 30.0, (n, 1, 1)) + rng.standard_normal((n, 1, 1))).astype(np.float64)
+    dev = torch.device("cuda", 0)
+    f_dev = torch.from_numpy(fields).to(dev)
+    tr_np = np.stack([rng.standard_normal(n) * 0.2, rng.uniform(0.1, 2.0, n)], 1)
+    tr = torch.from_numpy(tr_np).to(dev)
+    x = torch.empty((n, side, side), dtype=torch.float32, device=dev)
+    ain = torch.empty((n, 2), dtype=torch.float32, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None
+    L.check(L.lib.srcfd_prepare_inputs_device(p(f_dev), n, side, side, None, None, side, p(tr), 1, 0.3, p(x), p(ain), None))
+    torch.cuda.synchronize()
+    xg, ag = x.cpu().numpy(), ain.cpu().numpy()
+    for i in range(n):
+        x32 = fields[i].astype(np.float32)
+        np.testing.assert_array_equal(xg[i], x32)
+        input_mean, input_std = np.mean(x32), np.std(x32)      # the reference's expressions, bfs_ml_accelerated.py:1091-1097
+        # the training statistics are Python floats in the reference (parsed from the stats file): weak scalars next to np.float32
+        mean_lr = (1 - 0.3) * float(tr_np[i, 0]) + 0.3 * input_mean
+        std_lr = (1 - 0.3) * float(tr_np[i, 1]) + 0.3 * max(input_std, 1e-8)
+        want = np.array([mean_lr, std_lr], np.float32)
+        np.testing.assert_array_equal(ag[i].view(np.uint32), want.view(np.uint32), err_msg=f"side {side} sample {i}")
+
+
+@pytest.mark.gpu
 def test_verbose_call_prints_the_reference_style_report_and_same_fields(srcfd, decoder_h5, coarse_cases, capsys):
     """verbose=True reports the blended statistics and the range of every component (the reference prints them on every
     call, bfs_ml_accelerated.py:1096-1145); the quiet default skips those range scans but returns the same arrays."""

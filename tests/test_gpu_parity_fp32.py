@@ -60,9 +60,11 @@ def test_one_launch_f32_encoder_against_the_layer_by_layer_launches(srcfd, oracl
     ref = oracle.superres_forward(x[:6], enc_weights, dec_weights, np.float64)
     m = srcfd.SRModel.from_weights(enc_weights, dec_weights, device=0)
     y_new = m.predict(x[:6])
+    assert m.last_plan()["encoder"] == "enc32" and m.last_plan()["dense_1"] == "dense_skinny32"
     monkeypatch.setenv("SRCFD_NO_ENC32", "1")
     monkeypatch.setenv("SRCFD_NO_DENSE_SKINNY", "1")
     y_old = m.predict(x[:6])
+    assert m.last_plan()["encoder"] == "layers" and m.last_plan()["dense_1"] == "gemm32"   # the implementation that RAN
     monkeypatch.delenv("SRCFD_NO_ENC32")
     monkeypatch.delenv("SRCFD_NO_DENSE_SKINNY")
     assert oracle.rel_l2(y_new, ref) <= TOL_FP32 and oracle.rel_l2(y_old, ref) <= TOL_FP32

@@ -229,6 +229,32 @@ def test_whole_model_superres_file_round_trip(srcfd, enc_weights, dec_weights, t
                                   [(d["name"], d["stride"], d["same"], d["activation"], d["reshape"]) for d in m.layers()]
     for k in w1:
         np.testing.assert_array_equal(m3.weights()[k], w1[k])
+    # ... and ONLY for that architecture: the notebook's other variants carry the same layer names with other strides /
+    # paddings, which a weights-only file cannot express -- a 3x3 transposed kernel where the reference has 2x2 is refused
+    def weights_only(path, enc_w, dec_w):
+        ww = srcfd.H5Writer()
+        ww.attr("/", "keras_version", "3.8.0")
+        ww.attr("/", "backend", "tensorflow")
+        ww.attr("/", "model_config", '{"class_name": "SuperResolutionAE"}')
+        ww.group("model_weights")
+        ww.attr("/model_weights", "layer_names", ["encoder_10", "decoder_400"])
+        for sub, ws in (("encoder_10", enc_w), ("decoder_400", dec_w)):
+            ww.group(f"model_weights/{sub}")
+            ww.attr(f"/model_weights/{sub}", "weight_names", list(ws))
+            for k, v in ws.items():
+                ww.dataset(f"model_weights/{sub}/{k}", v)
+        ww.save(path)
+    other = dict(dec_weights)
+    k1 = dec_weights["conv2d_transpose_1/kernel"]
+    other["conv2d_transpose_1/kernel"] = np.zeros((3, 3) + k1.shape[2:], np.float32)      # Conv2DTranspose(.., 3, strides=2, padding='same') variant
+    bad = str(tmp_path / "superres_other_variant.h5")
+    weights_only(bad, enc_weights, other)
+    with pytest.raises(OSError, match="architecture not recoverable"):
+        srcfd.SRModel.load_superres_h5(bad, device=-1)
+    fewer = {k: v for k, v in dec_weights.items() if not k.startswith("conv2d_transpose_4/")}
+    weights_only(bad, enc_weights, fewer)
+    with pytest.raises(OSError, match="architecture not recoverable"):
+        srcfd.SRModel.load_superres_h5(bad, device=-1)
     # the sub-model pair written from it is what the solvers load (PyCFD_ML_accelerated.py:831-832)
     m3.save_h5(str(tmp_path / "e.h5"), str(tmp_path / "d.h5"))
     assert srcfd.SRModel.load_h5(str(tmp_path / "e.h5"), str(tmp_path / "d.h5"), device=-1).macs_per_sample == 140_024_128
