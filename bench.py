@@ -48,11 +48,78 @@ MACS_PER_SAMPLE = 140_024_128
 PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16/f16 MFMA (MI355X_MICROARCH.md)
 PEAK_FP32_TFLOPS = 157.3          # f32-input MFMA
 PEAK_HBM_GBS = 8000.0
+PRE_WARM_MS = 80.0                # untimed steps by wall time in front of the counted warm-up of an SR leg (clock ramp; Job.timed)
 REFUSED_ENV = ("SRCFD_TAIL_ABLATE", "SRCFD_MID_ABLATE", "SRCFD_TAIL_PROF")   # switch work off / add syncs: never a headline
+# A/B switches: each selects a complete second implementation of a stage (results stay right), but a line measured under one is
+# not the shipped path: refused like the diagnostic switches (SRCFD_BENCH_ALLOW_DIAG=1 marks the line INVALID instead)
+AB_ENV_OFF_WHEN_ZERO = ("SRCFD_ENC", "SRCFD_MID", "SRCFD_DENSE1")
+AB_ENV_ON_WHEN_SET = ("SRCFD_NO_ENC32", "SRCFD_NO_DENSE_SKINNY", "SRCFD_NO_TAIL32", "SRCFD_NO_GEMM32_BIG", "SRCFD_NO_PAIR", "SRCFD_NO_TRIPLE")
+AB_ENV_ANY_VALUE = ("SRCFD_TAIL", "SRCFD_TAIL_SEG", "SRCFD_MID_WAVES", "SRCFD_GRAPH", "SRCFD_LIB", "SRCFD_TRAIN_OVERLAP", "SRCFD_TRAIN_GRAPH",
+                    "SRCFD_TRAIN_FUSE")
 
 
 def srcfd_env():
     return {k: v for k, v in sorted(os.environ.items()) if k.startswith("SRCFD_")}
+
+
+def non_default_switches(env):
+    """SRCFD_* variables that change WHICH kernels run (diagnostic or A/B): a headline line is never reported under them."""
+    bad = [k for k in env if k in REFUSED_ENV and env[k] not in ("", "0")]
+    bad += [k for k in AB_ENV_OFF_WHEN_ZERO if k in env and env[k].strip() == "0"]
+    bad += [k for k in AB_ENV_ON_WHEN_SET if env.get(k, "") not in ("", "0")]
+    bad += [k for k in AB_ENV_ANY_VALUE if env.get(k, "") != ""]
+    return bad
+
+
+def gpu_state(pci_bus_id=None):
+    """Clocks / power of the device as the driver reports them ("state clocks/power mode"), read from sysfs -- plain
+    file reads: a process that has initialised the GPU must not start another program on this pool (so no rocm-smi / amd-smi child).
+    Read before and after the headline leg: an idle device reports its sleep clocks, which is the point -- the record shows in
+    which state the leg started.  pci_bus_id: "0000:75:00.0"-style id of the HIP device; None: the first card with clock files.
+    Never raises."""
+    import glob
+    out = {}
+    try:
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/pp_dpm_sclk"))
+        pick = None
+        for f in cards:
+            dev = os.path.dirname(f)
+            if pci_bus_id and os.path.basename(os.path.realpath(dev)).lower() == pci_bus_id.lower():
+                pick = dev
+                break
+        if pick is None and cards:
+            pick = os.path.dirname(cards[0])
+            out["note"] = "card not matched by PCI id: first card with clock files"
+        if pick is None:
+            return {"error": "no /sys/class/drm/card*/device/pp_dpm_sclk"}
+
+        def cur(name):
+            try:
+                for ln in open(os.path.join(pick, name)).read().splitlines():
+                    if ln.rstrip().endswith("*"):
+                        return ln.split(":", 1)[1].replace("*", "").strip()
+            except OSError:
+                return None
+            return None
+
+        def num(pattern, scale):
+            for f in glob.glob(os.path.join(pick, pattern)):
+                try:
+                    return round(int(open(f).read().strip()) / scale, 1)
+                except (OSError, ValueError):
+                    pass
+            return None
+
+        out.update({"card": os.path.basename(os.path.dirname(pick)), "sclk": cur("pp_dpm_sclk"), "mclk": cur("pp_dpm_mclk"), "fclk": cur("pp_dpm_fclk"),
+                    "power_W": num("hwmon/hwmon*/power1_average", 1e6) or num("hwmon/hwmon*/power1_input", 1e6),
+                    "power_cap_W": num("hwmon/hwmon*/power1_cap", 1e6)})
+        try:
+            out["perf_level"] = open(os.path.join(pick, "power_dpm_force_performance_level")).read().strip()
+        except OSError:
+            pass
+    except Exception as e:   # noqa: BLE001
+        out["error"] = f"{type(e).__name__}: {e}"[:120]
+    return out
 
 
 def parse_args(argv=None):
@@ -245,10 +312,20 @@ class Job:
         if self.world > 1:
             self.dist.barrier()
 
-    def timed(self, step, steps, warmup):
+    def timed(self, step, steps, warmup, pre_ms=0.0):
         """`warmup` untimed + exactly `steps` timed calls of `step`, bracketed by barrier + synchronize on both
-        sides; returns the MAX over ranks of the seconds the timed calls took."""
+        sides; returns the MAX over ranks of the seconds the timed calls took.  `pre_ms` > 0: BEFORE the counted warm-up
+        steps, untimed steps are issued until that much wall time has passed -- the first ~50 ms after an idle spell run ~10 %
+        slower (clock ramp), and with the driver's `--steps 20 --warmup 5` the whole 15 ms timed region would sit
+        inside it.  The counted steps and warm-up stay exactly as given.  self.last_rank_ms = (min, max) over ranks of the
+        per-step time, so a straggler is visible in an N > 1 line."""
         torch = self.torch
+        if pre_ms > 0:
+            t_pre = time.perf_counter()
+            while (time.perf_counter() - t_pre) * 1e3 < pre_ms:
+                for _ in range(4):
+                    step()
+                torch.cuda.synchronize()
         for _ in range(warmup):
             step()
         torch.cuda.synchronize()
@@ -258,9 +335,14 @@ class Job:
         for _ in range(steps):
             step()
         torch.cuda.synchronize()
+        mine = time.perf_counter() - t0
         self.barrier()
         torch.cuda.synchronize()
-        return self.shard.max_over_ranks(time.perf_counter() - t0, device=self.dev if self.backend == "nccl" else None)
+        dt = time.perf_counter() - t0
+        dev = self.dev if self.backend == "nccl" else None
+        self.last_rank_ms = (round(-self.shard.max_over_ranks(-mine, device=dev) / steps * 1e3, 4),
+                             round(self.shard.max_over_ranks(mine, device=dev) / steps * 1e3, 4))
+        return self.shard.max_over_ranks(dt, device=dev)
 
     def kernel_profile(self, step, reps):
         """Per-step kernel times from HIP events recorded by the engine on the launch stream around every
@@ -289,10 +371,11 @@ class Job:
         def step():
             self.model.predict_device(self.x, y, in_affine=self.ain, out_affine=self.aout, nan_guard=True, nonfinite=self.bad)
 
-        dt = self.timed(step, steps, warmup)
+        dt = self.timed(step, steps, warmup, pre_ms=PRE_WARM_MS)
         ms = dt / steps * 1e3
         rec = {"value": round(self.shard.aggregate_throughput(args.fields, self.world, ms * 1e-3), 2), "unit": "fields/s",
                "ms_per_step": round(ms, 4), "steps": steps, "dtype": precision, "out_dtype": out_dtype,
+               "ms_per_step_rank_min_max": list(self.last_rank_ms), "untimed_pre_warm_ms": PRE_WARM_MS,
                "tflops_model": round(2.0 * MACS_PER_SAMPLE * self.n * self.world / (ms * 1e-3) / 1e12, 2),
                "nonfinite": int(self.bad.item())}
         if self.rank == 0:
@@ -336,17 +419,41 @@ class Job:
 
     # -- config 4: training step ---------------------------------------------------------------------------------
     def run_train(self, steps=30, warmup=3, batch=8):
+        """BASELINE config 4: the weak-scaling leg (micro-batch 8 per GPU = the reference's BATCH_SIZE,
+        sr-ae-conv.ipynb:c386-388, global batch 8 G) is the record's `value`; `strong` holds the global-batch-256 regime
+        (256 / G samples per rank and step): accumulated from micro-batches of 8, and from calls of up to 32 samples."""
         np, torch = self.np, self.torch
         tr = importlib.import_module("sr-for-cfd_amd.train")
         ds = importlib.import_module("sr-for-cfd_amd.datasets")
         enc, dec = self.synth.keras_default_init(0)                     # identical replicas: same seed on every rank
         model = self.srcfd.SRModel.from_weights(enc, dec, device=self.local_rank)
-        t = tr.Trainer(model, max_batch=batch)
-        # the notebook's own dummy recipe (sr-ae-conv.ipynb:c72-91): x_hr ~ N(0,1), x_lr = avg_pool(x_hr, 40)
-        rng = np.random.default_rng(1000 + self.rank)
-        y_h = rng.standard_normal((batch, 400, 400, 1)).astype(np.float32)
-        x = torch.from_numpy(ds.avg_pool(y_h, 40)).to(self.dev)
-        y = torch.from_numpy(y_h).to(self.dev)
+        # set-up (allocations) first, agreed on by every rank BEFORE anything enters a collective: a rank that cannot allocate must
+        # not leave the others waiting in an all-reduce (ADVICE r2)
+        ok = 1
+        t = t32 = None
+        try:
+            t = tr.Trainer(model, max_batch=batch)
+            t32 = tr.Trainer(model, max_batch=32)
+            # the notebook's own dummy recipe (sr-ae-conv.ipynb:c72-91): x_hr ~ N(0,1), x_lr = avg_pool(x_hr, 40)
+            rng = np.random.default_rng(1000 + self.rank)
+            y_h = rng.standard_normal((32, 400, 400, 1)).astype(np.float32)
+            x32 = torch.from_numpy(ds.avg_pool(y_h, 40)).to(self.dev)
+            y32 = torch.from_numpy(y_h).to(self.dev)
+        except Exception as e:   # noqa: BLE001
+            ok, err = 0, f"{type(e).__name__}: {e}"[:200]
+        if self.world > 1:
+            flag = torch.tensor([ok], dtype=torch.int32, device=self.dev if self.backend == "nccl" else "cpu")
+            self.dist.all_reduce(flag, op=self.dist.ReduceOp.MIN)
+            all_ok = int(flag.item())
+        else:
+            all_ok = ok
+        if not all_ok:
+            for h_ in (t, t32):
+                if h_ is not None:
+                    h_.close()
+            model.close()
+            raise RuntimeError("training set-up failed on " + ("this rank: " + err if not ok else "another rank"))
+        x, y = x32[:batch].contiguous(), y32[:batch].contiguous()
         gb = batch * self.world
 
         def step():
@@ -360,14 +467,44 @@ class Job:
         t.sse.zero_()
         t.forward_backward(x, y, gb)
         loss = float(t.sse.item()) / (batch * 160000)
+        flops_per_sample = 3 * 2 * MACS_PER_SAMPLE
         rec = {"metric": "conv-AE training samples/s (10x10->400x400, f32, Adam; BASELINE config 4)", "value": round(gb / (ms * 1e-3), 2),
                "unit": "samples/s", "ms_per_step": round(ms, 4), "steps": steps, "warmup": warmup, "micro_batch": batch, "global_batch": gb,
                "scaling": "weak", "dtype": "f32", "params": t.n_params, "collective": "none" if self.world == 1 else
                f"all_reduce(sum) of {t.n_params} f32 per step, backend {self.backend}",
-               "tflops_model": round(3 * 2 * MACS_PER_SAMPLE * gb / (ms * 1e-3) / 1e12, 2),
-               "frac_f32_mfma_peak": round(3 * 2 * MACS_PER_SAMPLE * batch / (ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4),
+               "tflops_model": round(flops_per_sample * gb / (ms * 1e-3) / 1e12, 2),
+               "frac_f32_mfma_peak": round(flops_per_sample * batch / (ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4),
+               "ms_per_step_rank_min_max": list(self.last_rank_ms),
                "loss_finite": bool(np.isfinite(loss))}
+
+        # strong scaling: global batch 256, 256 / G samples per rank and optimiser step (sr-ae-conv.ipynb:c386-388 BATCH_SIZE scaled
+        # to the node).  Two ways to run a rank's share: micro-batches of 8 accumulated (the weak leg's kernels), and
+        # calls of up to 32 samples (the regime where the training kernels stop being launch latency)
+        GB = 256
+        per_rank = GB // self.world if GB % self.world == 0 else 0
+        strong = {"global_batch": GB, "samples_per_rank": per_rank}
+        if per_rank >= 8 and per_rank % 8 == 0:
+            for name, trn, mb in (("micro8", t, 8), ("calls_of_up_to_32", t32, min(32, per_rank))):
+                calls = per_rank // mb
+
+                def sstep(trn=trn, mb=mb, calls=calls):
+                    trn.grads.zero_()
+                    for c in range(calls):
+                        lo = (c * mb) % 32
+                        trn.forward_backward(x32[lo:lo + mb], y32[lo:lo + mb], GB)
+                    tr.allreduce_sum_(trn.grads)
+                    trn.apply_adam()
+
+                sdt = self.timed(sstep, max(4, steps // 5), 2)
+                sms = sdt / max(4, steps // 5) * 1e3
+                strong[name] = {"ms_per_step": round(sms, 4), "samples_per_s": round(GB / (sms * 1e-3), 1), "calls_per_step": calls, "call_batch": mb,
+                                "frac_f32_mfma_peak": round(flops_per_sample * per_rank / (sms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4),
+                                "ms_per_step_rank_min_max": list(self.last_rank_ms)}
+        else:
+            strong["skipped"] = f"256 is not a multiple of 8 x {self.world} ranks"
+        rec["strong"] = strong
         t.close()
+        t32.close()
         model.close()
         return rec
 
@@ -389,9 +526,9 @@ class Job:
             if n:
                 self.model.predict_device(x, y[:n], nan_guard=True, nonfinite=self.bad)
 
-        dt = self.timed(step, steps, warmup)
+        dt = self.timed(step, steps, warmup, pre_ms=PRE_WARM_MS / 2)
         ms = dt / steps * 1e3
-        return {"metric": "tiled SR fields/s (40x40x3 -> 1600x1600x3 via 4x4 tiles; BASELINE config 5)", "value": round(1.0 / (ms * 1e-3), 2),
+        return {"ms_per_step_rank_min_max": list(self.last_rank_ms), "metric": "tiled SR fields/s (40x40x3 -> 1600x1600x3 via 4x4 tiles; BASELINE config 5)", "value": round(1.0 / (ms * 1e-3), 2),
                 "unit": "fields/s", "ms_per_field": round(ms, 4), "steps": steps, "warmup": warmup, "dtype": "f16", "tile_samples": 48,
                 "tile_samples_this_rank": n, "scaling": "strong", "mpix_per_s": round(1600 * 1600 * 3 / (ms * 1e-3) / 1e6, 1)}
 
@@ -424,8 +561,9 @@ class Job:
 
 
 def dry_run(args, env):
-    """SRCFD_BENCH_DRYRUN=1: the rank plumbing only (process group, barrier, MAX over ranks, rank 0's line) with no
-    device work, so that `--gpus N` can be rehearsed on a box without GPUs (tests/test_distributed.py).  `value` is null."""
+    """SRCFD_BENCH_DRYRUN=1: the rank plumbing only (process group, barrier, MAX over ranks, the legs' shard arithmetic, the
+    all-or-none agreement after a leg, rank 0's line) with no device work, so that `--gpus N` -- N = 8 included -- can be rehearsed
+    on a box without GPUs (tests/test_distributed.py).  `value` is null."""
     import torch
     import torch.distributed as dist
     shard = importlib.import_module("sr-for-cfd_amd.shard")
@@ -435,14 +573,24 @@ def dry_run(args, env):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         dist.barrier()
     t = shard.max_over_ranks(float(rank + 1))
+    tmin = -shard.max_over_ranks(-float(rank + 1))
     lo, hi = shard.shard_range(48, rank, world)
-    cnt = torch.tensor([hi - lo], dtype=torch.int64)
+    counts = torch.zeros(world, dtype=torch.int64)
+    counts[rank] = hi - lo
+    # what every rank would hold: the headline batch, the f32 parity workspace, the trainers -- host-side estimate of the
+    # device bytes reserve() asks for per rank (8 ranks share one host's memory for their staging copies only)
+    fail = torch.tensor([1 if os.environ.get("SRCFD_BENCH_DRYRUN_FAIL_RANK", "") == str(rank) else 0], dtype=torch.int32)
     if world > 1:
-        dist.all_reduce(cnt)
+        dist.all_reduce(counts)
+        dist.all_reduce(fail, op=dist.ReduceOp.MAX)
+    per_rank_256 = 256 // world if 256 % world == 0 else 0
     if rank == 0:
         print(json.dumps({"metric": "SR fields/sec (10x10->400x400, 3-ch) @batch256", "value": None, "unit": "fields/s", "dry_run": True,
                           "n_gpus": world, "world_size_reported": dist.get_world_size() if world > 1 else 1, "steps": args.steps,
-                          "warmup": args.warmup, "max_over_ranks": t, "tile_samples_covered": int(cnt.item()), "env": env}))
+                          "warmup": args.warmup, "max_over_ranks": t, "min_over_ranks": tmin, "tile_samples_covered": int(counts.sum().item()),
+                          "tile_samples_per_rank": [int(c) for c in counts], "fields_total": args.fields * world,
+                          "train": {"global_batch": 8 * world, "strong": {"global_batch": 256, "samples_per_rank": per_rank_256}},
+                          "leg_failed_somewhere": bool(fail.item()), "env": env}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -451,9 +599,10 @@ def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
     env = srcfd_env()
-    bad_env = [k for k in env if k in REFUSED_ENV and env[k] not in ("", "0")]
+    bad_env = non_default_switches(env)
     if bad_env and os.environ.get("SRCFD_BENCH_ALLOW_DIAG", "0") in ("", "0"):
-        raise SystemExit(f"bench.py: diagnostic switches {bad_env} are set: they skip work or add synchronisation; refusing to report a number")
+        raise SystemExit(f"bench.py: {bad_env} set: diagnostic switches skip work or add synchronisation, A/B switches select another "
+                         "implementation than the shipped one; refusing to report a number (SRCFD_BENCH_ALLOW_DIAG=1 reports an INVALID line)")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args, argv))
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
@@ -487,13 +636,22 @@ def main():
     extra_errors = {}
 
     def leg(name, fn):
-        """A sub-record must never cost the headline: an exception in one (on every rank alike: same code, same data shapes)
-        is recorded in the line instead of ending the run."""
+        """A sub-record must never cost the headline: an exception in one is recorded in the line instead of ending the run.  With
+        several ranks the legs' collectives must be entered by all or none: a leg does its allocations first and agrees on them
+        (run_train); after every leg the ranks agree on its outcome, so a failure anywhere is recorded everywhere."""
+        res, failed = None, 0
         try:
-            return fn()
+            res = fn()
         except Exception as e:   # noqa: BLE001
             extra_errors[name] = f"{type(e).__name__}: {e}"[:300]
-            return None
+            failed = 1
+        if job.world > 1:
+            flag = torch.tensor([failed], dtype=torch.int32, device=job.dev if job.backend == "nccl" else "cpu")
+            job.dist.all_reduce(flag, op=job.dist.ReduceOp.MAX)
+            if int(flag.item()) and not failed:
+                extra_errors[name] = "failed on another rank"
+                res = None
+        return res
 
     # Order of the legs: the f32 parity path first (parity is the gate; it also means the headline's W warm-up steps do not
     # start on a GPU that has idled through model loading and weight packing), then the headline, then the other sub-records.
@@ -505,7 +663,15 @@ def main():
             return rec
         parity = leg("parity_path", _parity)
 
+    pci = None
+    try:
+        pr = torch.cuda.get_device_properties(job.local_rank)
+        pci = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+    except Exception:   # noqa: BLE001
+        pass
+    gpu_before = gpu_state(pci) if job.rank == 0 else None
     head, y_head = job.run_sr(args.precision, args.out_dtype, args.steps, args.warmup)
+    gpu_after = gpu_state(pci) if job.rank == 0 else None
     if job.rank == 0 and job.world == 1 and not args.no_cpu_baseline and args.out_dtype == "f32":
         y_gpu[args.precision] = y_head[:8].cpu().numpy()
     del y_head
@@ -540,12 +706,13 @@ def main():
             "roofline": head.get("roofline"),
             "cpu_baseline": cpu,
             "parity_path": parity, "train": train, "tiled": tiled, "host_io": host_io,
-            "env": env,
+            "ms_per_step_rank_min_max": head.get("ms_per_step_rank_min_max"), "untimed_pre_warm_ms": head.get("untimed_pre_warm_ms"),
+            "env": dict(env, gpu_state_before_headline=gpu_before, gpu_state_after_headline=gpu_after),
         }
         if extra_errors:
             out["sub_record_errors"] = extra_errors
         if bad_env:
-            out["INVALID_diagnostic_run"] = bad_env   # SRCFD_BENCH_ALLOW_DIAG=1 with a DIAG=1 build: tools/ablate*.sh only
+            out["INVALID_diagnostic_run"] = bad_env   # SRCFD_BENCH_ALLOW_DIAG=1: tools/ablate*.sh and A/B timing only
         print(json.dumps(out))
     if job.world > 1:
         job.dist.destroy_process_group()

@@ -149,8 +149,8 @@ int srcfd_model_get_profile(srcfd_model* m, char* names, size_t names_len, float
  * the default fused ConvT#0->ConvT#1 kernel never materialises it. */
 int srcfd_model_debug_activation(srcfd_model* m, int index, void* dst, size_t bytes);
 /* Test hook: which implementation of each stage the handle's LAST forward ran, as "key=value" words separated by blanks, e.g.
- * "precision=bf16 encoder=enc16 dense_1=dense1_16 middle=mid16 tail_seg=10 graph=replay".  The A/B switches SRCFD_ENC,
- * SRCFD_DENSE1, SRCFD_MID, SRCFD_NO_ENC32, SRCFD_NO_DENSE_SKINNY and SRCFD_TAIL_SEG are read from the environment on every
+ * "precision=bf16 encoder=enc16 dense_1=dense1_16 middle=mid16 tail=tail16 tail_seg=10 graph=replay".  The A/B switches SRCFD_ENC,
+ * SRCFD_DENSE1, SRCFD_MID, SRCFD_TAIL (=s), SRCFD_NO_ENC32, SRCFD_NO_DENSE_SKINNY and SRCFD_TAIL_SEG are read from the environment on every
  * srcfd_predict* call; each selects a complete second implementation (the parity tests compare the two), none skips work, and a
  * captured hipGraph is replayed only under the switches it was captured with.  graph: eager | capture | replay. */
 int srcfd_model_last_plan(const srcfd_model* m, char* buf, size_t buf_len);

@@ -40,11 +40,13 @@ struct Switches {
   bool dense1_16 = true; // SRCFD_DENSE1=0: dense_1 on the generic 16-bit GEMM
   bool enc32 = true;     // SRCFD_NO_ENC32=1: layer-by-layer f32 encoder
   bool skinny32 = true;  // SRCFD_NO_DENSE_SKINNY=1: dense_1 on the generic f32 GEMM
+  bool tail16s = false;  // SRCFD_TAIL=s: the software-pipelined 8-wave tail kernel (kernels_tail16.hip) instead of the 16-wave, stage-by-stage one (measured slower)
   int tail_seg = 0;      // SRCFD_TAIL_SEG: segments per sample of the 16-bit tail (1, 2, 5, 10, 25); 0 = chosen per batch
   unsigned bits() const {
-    return (enc16 ? 1u : 0u) | (mid16 ? 2u : 0u) | (dense1_16 ? 4u : 0u) | (enc32 ? 8u : 0u) | (skinny32 ? 16u : 0u) | ((unsigned)tail_seg << 8);
+    return (enc16 ? 1u : 0u) | (mid16 ? 2u : 0u) | (dense1_16 ? 4u : 0u) | (enc32 ? 8u : 0u) | (skinny32 ? 16u : 0u) | (tail16s ? 32u : 0u) |
+           ((unsigned)tail_seg << 8);
   }
-  bool all_default() const { return enc16 && mid16 && dense1_16 && enc32 && skinny32 && tail_seg == 0; }
+  bool all_default() const { return enc16 && mid16 && dense1_16 && enc32 && skinny32 && !tail16s && tail_seg == 0; }
   static Switches from_env();
 };
 

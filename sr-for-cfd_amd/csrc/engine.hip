@@ -303,6 +303,7 @@ Switches Switches::from_env() {
   w.dense1_16 = on("SRCFD_DENSE1", true);
   w.enc32 = !on("SRCFD_NO_ENC32", false);
   w.skinny32 = !on("SRCFD_NO_DENSE_SKINNY", false);
+  { const char* t = getenv("SRCFD_TAIL"); w.tail16s = t && t[0] == 's'; }
   const char* e = getenv("SRCFD_TAIL_SEG");
   const int seg = e ? atoi(e) : 0;
   w.tail_seg = (seg == 1 || seg == 2 || seg == 5 || seg == 10 || seg == 25) ? seg : 0;
@@ -896,8 +897,8 @@ int srcfd_model_last_plan(const srcfd_model* m, char* buf, size_t buf_len) {
   const char* prec = p.precision == SRCFD_PREC_BF16 ? "bf16" : p.precision == SRCFD_PREC_F16 ? "f16" : p.precision == SRCFD_PREC_FP32 ? "fp32" : "fp32_naive";
   char tmp[256];
   if (p.fused)
-    snprintf(tmp, sizeof(tmp), "precision=%s encoder=%s dense_1=%s middle=%s tail_seg=%d graph=%s", prec, p.sw.enc16 ? "enc16" : "layers",
-             p.sw.dense1_16 ? "dense1_16" : "gemm16", p.sw.mid16 ? "mid16" : "gemm16", p.tail_seg,
+    snprintf(tmp, sizeof(tmp), "precision=%s encoder=%s dense_1=%s middle=%s tail=%s tail_seg=%d graph=%s", prec, p.sw.enc16 ? "enc16" : "layers",
+             p.sw.dense1_16 ? "dense1_16" : "gemm16", p.sw.mid16 ? "mid16" : "gemm16", p.sw.tail16s ? "tail16s" : "tail16", p.tail_seg,
              p.graph == 2 ? "replay" : p.graph == 1 ? "capture" : "eager");
   else
     snprintf(tmp, sizeof(tmp), "precision=%s encoder=%s dense_1=%s graph=%s", prec, p.sw.enc32 ? "enc32" : "layers",

@@ -463,7 +463,7 @@ int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, cons
     static unsigned long long* d_prof = nullptr;   // SRCFD_TAIL_PROF=1: per-wave section timers of workgroup 0 (synchronises: never under graph capture)
     static int prof_calls = 0;
     static const bool prof = getenv("SRCFD_TAIL_PROF") != nullptr;
-    if (prof && !d_prof) HIPCHECK(hipMalloc(&d_prof, 16 * 5 * sizeof(unsigned long long)));
+    if (prof && !d_prof) HIPCHECK(hipMalloc(&d_prof, 128 * sizeof(unsigned long long)));
     tp.prof = prof ? d_prof : nullptr;
 #endif
     // Batches that do not fill the chip evenly (fewer samples than CUs, or a few more than a multiple of them): cut each
@@ -482,16 +482,30 @@ int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, cons
     tp.seg = seg;
     m.plan.tail_seg = seg;
     const int blocks = std::min(c * seg, fs->num_cus);
-    rc = m.launch("tail(convT2-4+out)", s, [&] { return launch_tail16(f16, tp, blocks, s); });
+    const bool tail_s = m.sw.tail16s;
+    rc = m.launch("tail(convT2-4+out)", s, [&] { return tail_s ? launch_tail16s(f16, tp, blocks, s) : launch_tail16(f16, tp, blocks, s); });
     if (rc) return rc;
 #ifdef SRCFD_DIAG
     if (prof && ++prof_calls == 20) {
-      unsigned long long h[80];
+      unsigned long long h[128];
       HIPCHECK(hipStreamSynchronize(s));
       HIPCHECK(hipMemcpy(h, d_prof, sizeof(h), hipMemcpyDeviceToHost));
-      fprintf(stderr, "tail16 workgroup 0, cycles per wave: D, BC, A, barrier wait, total\n");
-      for (int w = 0; w < 16; ++w)
-        fprintf(stderr, "  wave %2d: %9llu %9llu %9llu %9llu %9llu\n", w, h[w * 5], h[w * 5 + 1], h[w * 5 + 2], h[w * 5 + 3], h[w * 5 + 4]);
+      if (tail_s) {
+        fprintf(stderr, "tail16s workgroup 0, per wave: fast rounds (work cycles, barrier wait cycles, count) | other rounds (work, wait, count)\n");
+        for (int w = 0; w < 8; ++w)
+          fprintf(stderr, "  wave %d: %9llu %9llu %5llu | %9llu %9llu %5llu   per fast round: work %6.0f wait %6.0f\n", w, h[w * 6], h[w * 6 + 1], h[w * 6 + 2],
+                  h[w * 6 + 3], h[w * 6 + 4], h[w * 6 + 5], h[w * 6 + 2] ? (double)h[w * 6] / h[w * 6 + 2] : 0.0, h[w * 6 + 2] ? (double)h[w * 6 + 1] / h[w * 6 + 2] : 0.0);
+        fprintf(stderr, "  cycles per fast round and section (top, then the blocks in issue order):\n");
+        for (int w = 0; w < 8; ++w) {
+          fprintf(stderr, "  wave %d:", w);
+          for (int i = 0; i < 10; ++i) fprintf(stderr, " %6.0f", h[w * 6 + 2] ? (double)h[48 + w * 10 + i] / h[w * 6 + 2] : 0.0);
+          fprintf(stderr, "\n");
+        }
+      } else {
+        fprintf(stderr, "tail16 workgroup 0, cycles per wave: D, BC, A, barrier wait, total\n");
+        for (int w = 0; w < 16; ++w)
+          fprintf(stderr, "  wave %2d: %9llu %9llu %9llu %9llu %9llu\n", w, h[w * 5], h[w * 5 + 1], h[w * 5 + 2], h[w * 5 + 3], h[w * 5 + 4]);
+      }
     }
 #endif
   }

@@ -18,6 +18,7 @@
 
 #include "dev16.h"
 #include "kernels16.h"
+#include "tail16_layout.h"
 
 namespace srcfd {
 
@@ -303,27 +304,6 @@ __global__ void __launch_bounds__(256) splitk_finish16(const float* __restrict__
 //  L100 (100-level, 4 chunks of 8 channels): [chunk][row][x parity][x >> 1];
 //    A writes pixels 2 apart (-> consecutive), BC reads consecutive pixels
 //    (parity planes 56 granules = 8 mod 16 apart -> conflict-free).
-constexpr int T_RING_ROWS = 18, T_PLANE = 52, T_ROWP = 8 * T_PLANE * 16;   // 50 granules + a zero granule at either end of a plane
-constexpr int T_OFF_RING = 0;
-constexpr int T_OFF_L100 = T_RING_ROWS * T_ROWP;            // 119808
-constexpr int T_L100_BUF = 4 * 212 * 16;                    // 13568
-constexpr int T_OFF_CONST = T_OFF_L100 + 2 * T_L100_BUF;    // blob copied from TailParams::consts
-constexpr int T_OFF_CTR = T_OFF_CONST + TAIL_CONST_BYTES;
-constexpr int T_OFF_ZERO = T_OFF_CTR + 16;                  // 16 zero bytes: what out-of-image window pixels read
-constexpr int T_LDS_BYTES = T_OFF_ZERO + 16;
-static_assert(T_LDS_BYTES <= 160 * 1024, "tail kernel LDS budget");
-
-__device__ __forceinline__ int ring_off(int Y, int X) { return (Y % T_RING_ROWS) * T_ROWP + (((X & 7) * T_PLANE + (X >> 3) + 1) << 4); }
-__device__ __forceinline__ int l100_off(int a, int x, int chunk) { return (chunk * 212 + a * 106 + (x & 1) * 56 + (x >> 1)) << 4; }
-
-// block-wide barrier that leaves global loads / stores in flight: only LDS traffic
-// has to be complete before the other waves may look at it
-__device__ __forceinline__ void lds_barrier() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
-
 // Diagnostic work-skipping switches (TailParams::ablate) exist only in a -DSRCFD_DIAG build (make DIAG=1): the shipped
 // kernels carry no path that turns work off.
 #ifdef SRCFD_DIAG

@@ -9,6 +9,14 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 ENCODER_H5 = os.path.join(GOLDEN, "vanilla_encoder10_to_400_swish_trained_upto_700_multiBC.h5")
 STATS_TXT = os.path.join(GOLDEN, "standardization_stats_10to400_swish_trained_upto_700_multiBC.txt")
+# All three trained encoder weight sets the reference checkout holds (the decoder / whole-model files are absent upstream), each with
+# the statistics file its `other_details` suffix selects (PyCFD_ML_accelerated.py:1376,1442-1444); data fixtures, MIT-licensed
+ENCODER_SETS = {
+    "multiBC": ("vanilla_encoder10_to_400_swish_trained_upto_700_multiBC.h5", "standardization_stats_10to400_swish_trained_upto_700_multiBC.txt"),
+    "upto_700": ("vanilla_encoder10_to_400_swish_trained_upto_700.h5", "standardization_stats_10to400_swish_trained_upto_700.txt"),
+    "68+23_multiBC": ("vanilla_encoder10_to_400_swish_trained_upto_700(68+23 samples)_multiBC.h5",
+                      "standardization_stats_10to400_swish_trained_upto_700(68+23 samples)_multiBC.txt"),
+}
 COARSE = {
     "bfs_Re400": "coarse_bfs_Re400.h5",
     "ldc_Re800_single": "coarse_ldc_Re800_single_lid.h5",

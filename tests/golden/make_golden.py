@@ -11,6 +11,8 @@ pin the oracle against regressions and give the GPU tests fixed targets:
   probe_*      64 fixed pixels + L2 norm + sum of the 400x400 output of
                real-encoder + synthetic decoder (seed 1) for 3 samples
   enc_checksum float64 sums of the encoder tensors as read by libsrcfd's HDF5 reader
+  latent3_*    the same latents for ALL THREE trained encoder files of the reference, each with its own statistics file
+               (keys latent3_<set>, x3_<set>; sets: conftest.ENCODER_SETS), + per-file tensor checksums enc3_checksum_<set>
 
 Run from the repo root:  python tests/golden/make_golden.py
 """
@@ -24,7 +26,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import srcfd_amd  # noqa: E402
-from conftest import COARSE, ENCODER_H5, GOLDEN, STATS_TXT  # noqa: E402
+from conftest import COARSE, ENCODER_H5, ENCODER_SETS, GOLDEN, STATS_TXT  # noqa: E402
 from oracle import sr_oracle as o  # noqa: E402
 
 
@@ -57,6 +59,18 @@ def main():
     names = sorted(enc)
     out["enc_names"] = np.array(names)
     out["enc_checksum"] = np.array([enc[k].astype(np.float64).sum() for k in names])
+    for key, (h5, txt) in ENCODER_SETS.items():
+        enc3 = srcfd_amd.SRModel.load_h5(os.path.join(GOLDEN, h5), None, device=-1).weights()
+        lr3, _ = o.component_stats(o.parse_stats(os.path.join(GOLDEN, txt)), 10, 400)
+        xs3 = []
+        for name, fn in COARSE.items():
+            case = srcfd_amd.read_coarse_fields(os.path.join(GOLDEN, fn))
+            for c in o.COMPONENTS:
+                xs3.append(o.standardize_with_stats(case[c].astype(np.float32), *lr3[c]).astype(np.float32))
+        x3 = np.stack(xs3)[..., None]
+        out[f"x3_{key}"] = x3
+        out[f"latent3_{key}"] = o.encoder_forward(x3, enc3, np.float64)
+        out[f"enc3_checksum_{key}"] = np.array([enc3[k].astype(np.float64).sum() for k in sorted(enc3)])
     np.savez_compressed(os.path.join(GOLDEN, "golden_vectors.npz"), **out)
     print({k: getattr(v, "shape", None) for k, v in out.items()})
 

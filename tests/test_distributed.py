@@ -135,12 +135,35 @@ def test_bench_gpus_flag_starts_that_many_ranks():
     assert r["env"] == {"SRCFD_BENCH_DRYRUN": "1"}          # every SRCFD_* variable is recorded in the line
 
 
+def test_bench_eight_rank_rehearsal():
+    """`bench.py --gpus 8` as the driver's 8-GPU node will run it, rehearsed with gloo and no device work: eight ranks come up,
+    the 48 tile samples of config 5 shard 6 per rank, the training legs see global batch 64 (weak) and 32 samples per rank
+    (strong, global batch 256), min / max over ranks are both reduced, and the outcome of a leg that fails on ONE rank is known
+    on every rank (the all-or-none agreement that keeps the others out of a collective)."""
+    rc, recs, err = _run_bench(["--gpus", "8", "--steps", "3", "--warmup", "1"], {"SRCFD_BENCH_DRYRUN": "1"})
+    assert rc == 0, err[-2000:]
+    r = recs[0]
+    assert r["n_gpus"] == 8 and r["world_size_reported"] == 8 and r["fields_total"] == 8 * 256
+    assert r["tile_samples_per_rank"] == [6] * 8 and r["tile_samples_covered"] == 48
+    assert r["train"]["global_batch"] == 64 and r["train"]["strong"] == {"global_batch": 256, "samples_per_rank": 32}
+    assert r["max_over_ranks"] == 8.0 and r["min_over_ranks"] == 1.0 and r["leg_failed_somewhere"] is False
+    rc, recs, err = _run_bench(["--gpus", "8", "--steps", "3", "--warmup", "1"], {"SRCFD_BENCH_DRYRUN": "1", "SRCFD_BENCH_DRYRUN_FAIL_RANK": "5"})
+    assert rc == 0 and recs[0]["leg_failed_somewhere"] is True
+
+
 def test_bench_refuses_mismatched_world_and_diagnostic_switches():
     rc, recs, err = _run_bench(["--gpus", "4"], {"SRCFD_BENCH_DRYRUN": "1", "WORLD_SIZE": "2", "RANK": "0"})
     assert rc != 0 and not recs and "WORLD_SIZE=2" in err
     for var in ("SRCFD_TAIL_ABLATE", "SRCFD_MID_ABLATE", "SRCFD_TAIL_PROF"):
         rc, recs, err = _run_bench([], {var: "1"})
         assert rc != 0 and not recs and var in err
+    # A/B switches select another implementation than the shipped one: no headline under them either (VERDICT r2 item 6)
+    for var, val in (("SRCFD_ENC", "0"), ("SRCFD_MID", "0"), ("SRCFD_DENSE1", "0"), ("SRCFD_NO_ENC32", "1"), ("SRCFD_NO_DENSE_SKINNY", "1"),
+                     ("SRCFD_TAIL", "s"), ("SRCFD_TAIL_SEG", "5"), ("SRCFD_LIB", "/nonexistent/libsrcfd.so")):
+        rc, recs, err = _run_bench([], {var: val})
+        assert rc != 0 and not recs and var in err, (var, err[-300:])
+    rc, recs, err = _run_bench(["--gpus", "2"], {"SRCFD_BENCH_DRYRUN": "1", "SRCFD_ENC": "1"})   # the default value of a switch is no switch
+    assert rc == 0 and len(recs) == 1
 
 
 @pytest.mark.gpu

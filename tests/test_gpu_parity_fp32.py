@@ -50,6 +50,44 @@ def test_encoder_latents_real_weights(srcfd, oracle, enc_weights, coarse_cases, 
     assert oracle.rel_l2(z.reshape(15, -1), ref) <= TOL_FP32
 
 
+@pytest.mark.parametrize("key", ["multiBC", "upto_700", "68+23_multiBC"])
+def test_all_three_trained_encoders_on_the_gpu(srcfd, oracle, key, monkeypatch):
+    """The one-launch encoders (enc32 f32, enc16 bf16 / f16) and the layer-by-layer chains they replace, on every trained weight set
+    the reference holds, with the statistics file that belongs to it: latents of the 15 real coarse fields against the committed
+    float64 vectors (f32 <= 1e-5; 16-bit within its stated bound), the two implementations of each precision close to each other."""
+    require_gpu(srcfd)
+    import os
+    from conftest import ENCODER_SETS, GOLDEN
+    g = np.load(os.path.join(GOLDEN, "golden_vectors.npz"))
+    h5, _ = ENCODER_SETS[key]
+    x, ref = g[f"x3_{key}"], g[f"latent3_{key}"]
+    m = srcfd.SRModel.load_h5(os.path.join(GOLDEN, h5), None, device=0)     # f32: encoder-only handles run every precision the graph allows
+    z32 = m.predict(x).reshape(15, -1)
+    assert m.last_plan()["encoder"] == "enc32"
+    assert oracle.rel_l2(z32, ref) <= TOL_FP32
+    monkeypatch.setenv("SRCFD_NO_ENC32", "1")
+    z32_chain = m.predict(x).reshape(15, -1)
+    assert m.last_plan()["encoder"] == "layers"
+    monkeypatch.delenv("SRCFD_NO_ENC32")
+    assert oracle.rel_l2(z32_chain, ref) <= TOL_FP32 and oracle.rel_l2(z32, z32_chain) <= 2e-6
+    # the 16-bit encoders need the whole encoder_10 + decoder_400 graph: attach the synthetic decoder and compare full outputs between
+    # enc16 and the layer-by-layer chain, and against the float64 oracle with THIS encoder
+    dec = oracle.synthetic_decoder(1)
+    w = srcfd.SRModel.load_h5(os.path.join(GOLDEN, h5), None, device=-1).weights()
+    full = srcfd.SRModel.from_weights(w, dec, device=0)
+    yref = oracle.superres_forward(x[:4], w, dec, np.float64)
+    for kind, tol in (("bf16", 2e-2), ("f16", 3e-3)):
+        full.precision = kind
+        y_enc = full.predict(x[:4])
+        assert full.last_plan()["encoder"] == "enc16"
+        monkeypatch.setenv("SRCFD_ENC", "0")
+        y_chain = full.predict(x[:4])
+        assert full.last_plan()["encoder"] == "layers"
+        monkeypatch.delenv("SRCFD_ENC")
+        assert oracle.rel_l2(y_enc, yref) <= tol and oracle.rel_l2(y_chain, yref) <= tol
+        assert oracle.rel_l2(y_enc, y_chain) <= tol
+
+
 def test_one_launch_f32_encoder_against_the_layer_by_layer_launches(srcfd, oracle, enc_weights, dec_weights, coarse_cases, monkeypatch):
     """enc32 (standardise + conv2d + conv2d_1 + dense + latent_vector in one kernel, 3 samples per workgroup) and dense_skinny32
     (dense_1) against the generic launches they replace (SRCFD_NO_ENC32 / SRCFD_NO_DENSE_SKINNY): both inside the 1e-5 bar, within

@@ -156,6 +156,31 @@ def test_golden_vectors(oracle, enc_weights, dec_weights):
         assert enc_weights[str(name)].astype(np.float64).sum() == cs
 
 
+def test_all_three_trained_encoders_load_and_match_their_golden_latents(srcfd, oracle):
+    """Every trained weight set the reference checkout holds (its decoder files are absent): the legacy-H5 reader on all three
+    files -- one of the names carries parentheses, a '+' and a blank -- the stats file its suffix selects, and the float64 oracle's
+    latents on the 15 real coarse fields against the committed vectors (the three sets are different trainings: their latents differ)."""
+    import torch
+    from conftest import ENCODER_SETS
+    from oracle.sr_oracle_torch import TorchSR  # noqa: F401  (second implementation, used below through encoder_forward_torch)
+    g = np.load(os.path.join(GOLDEN, "golden_vectors.npz"))
+    seen = []
+    for key, (h5, txt) in ENCODER_SETS.items():
+        m = srcfd.SRModel.load_h5(os.path.join(GOLDEN, h5), None, device=-1)
+        w = m.weights()
+        assert m.input_shape == (10, 10, 1) and m.output_shape == (1, 1, 50) and len(w) == 8
+        for name, cs in zip(sorted(w), g[f"enc3_checksum_{key}"]):
+            assert w[name].astype(np.float64).sum() == cs
+        lr, hr = srcfd.load_stats(os.path.join(GOLDEN, txt), 10, 400)
+        o_lr, _ = oracle.component_stats(oracle.parse_stats(os.path.join(GOLDEN, txt)), 10, 400)
+        assert lr == o_lr and all(s > 0 for _, s in lr.values())
+        z = oracle.encoder_forward(g[f"x3_{key}"], w, np.float64)
+        np.testing.assert_allclose(z, g[f"latent3_{key}"], rtol=1e-12, atol=1e-12)
+        seen.append(g[f"latent3_{key}"])
+    assert not np.allclose(seen[0], seen[1], atol=1e-3) and not np.allclose(seen[0], seen[2], atol=1e-3)
+    np.testing.assert_array_equal(g["latent3_multiBC"], g["latent_std"])      # the multiBC set is the one the other fixtures use
+
+
 def test_work_per_sample_matches_survey(srcfd, oracle, enc_weights, dec_weights):
     m = srcfd.SRModel.from_weights(enc_weights, dec_weights, device=-1)
     assert m.macs_per_sample == oracle.MACS_PER_SAMPLE == 140_024_128
