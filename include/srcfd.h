@@ -130,6 +130,13 @@ int srcfd_predict(srcfd_model* m, const float* x, int n, const float* in_affine,
  * SRCFD_BF16 or SRCFD_F16), nonfinite_dev an optional device int64 counter
  * that is ADDED to.  Enqueues on hip_stream (a hipStream_t, NULL = default
  * stream) and returns without synchronising. */
+/* Page-locked host memory for the arrays handed to srcfd_predict.  A result (y) that lives in such memory -- from here, or any
+ * hipHostMalloc / hipHostRegister'ed range -- is filled at the PCIe rate with the copy of one chunk overlapping the kernels of the
+ * next; a pageable result is staged by the runtime (about 45 GB/s, nothing overlaps) and, when freshly allocated, also pays its
+ * first-touch page faults.  The Python surface keeps a recycling pool of these behind predict() (engine.py). */
+int srcfd_host_alloc(size_t bytes, void** out);
+void srcfd_host_free(void* p);
+
 int srcfd_predict_device(srcfd_model* m, const void* x_dev, int n, const float* in_affine_dev,
                          const float* out_affine_dev, void* y_dev, int out_dtype, int flags,
                          int64_t* nonfinite_dev, void* hip_stream);

@@ -103,6 +103,8 @@ _protos = {
     "srcfd_model_get_profile": (C.c_int, [_p, C.c_char_p, _sz, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]),
     "srcfd_model_debug_activation": (C.c_int, [_p, C.c_int, _p, _sz]),
     "srcfd_model_last_plan": (C.c_int, [_p, C.c_char_p, _sz]),
+    "srcfd_host_alloc": (C.c_int, [_sz, C.POINTER(C.c_void_p)]),
+    "srcfd_host_free": (None, [_p]),
     "srcfd_model_save_h5": (C.c_int, [_p, C.c_char_p, C.c_char_p]),
     "srcfd_resampler_create": (C.c_int, [C.c_int, _p, _p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_p)]),
     "srcfd_resampler_destroy": (None, [_p]),

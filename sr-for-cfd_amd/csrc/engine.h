@@ -93,9 +93,12 @@ struct Model {
   size_t solver_state_elems = 0;
   size_t splitk_floats = 0;
   float* d_x_stage = nullptr;
-  float* d_y_stage = nullptr;
+  float* d_y_stage = nullptr;    // host-buffer entry: result of the chunk being computed ...
+  float* d_y_stage2 = nullptr;   // ... and of the chunk being copied out (page-locked destinations: copy and compute overlap)
   float* d_aff = nullptr;
   int stage_chunk = 0;
+  hipStream_t copy_stream = nullptr;
+  hipEvent_t ev_computed[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
   unsigned long long* d_nonfinite = nullptr;
 
   bool profiling = false;

@@ -317,7 +317,13 @@ void Model::drop_graph() {
 
 void Model::free_workspace() {
   for (int i = 0; i < 2; ++i) if (buf[i]) { (void)hipFree(buf[i]); buf[i] = nullptr; }
-  for (void* p : {(void*)d_x_stage, (void*)d_y_stage, (void*)d_aff, (void*)d_nonfinite, (void*)d_splitk, (void*)d_solver_state}) if (p) (void)hipFree(p);
+  for (void* p : {(void*)d_x_stage, (void*)d_y_stage, (void*)d_y_stage2, (void*)d_aff, (void*)d_nonfinite, (void*)d_splitk, (void*)d_solver_state}) if (p) (void)hipFree(p);
+  d_y_stage2 = nullptr;
+  if (copy_stream) { (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
+  for (int b = 0; b < 2; ++b) {
+    if (ev_computed[b]) { (void)hipEventDestroy(ev_computed[b]); ev_computed[b] = nullptr; }
+    if (ev_copied[b]) { (void)hipEventDestroy(ev_copied[b]); ev_copied[b] = nullptr; }
+  }
   d_solver_state = nullptr; solver_state_elems = 0; d_splitk = nullptr; splitk_floats = 0;
   d_x_stage = d_y_stage = nullptr; d_aff = nullptr; d_nonfinite = nullptr;
   ws_chunk = 0; stage_chunk = 0; ws_per_sample = 0;
@@ -620,30 +626,63 @@ int Model::predict_host(const float* x, int n, const float* aff_in, const float*
   const size_t in_elems = (size_t)desc.in_shape[0] * desc.in_shape[1] * desc.in_shape[2];
   const int* os = desc.out_shape();
   const size_t out_elems = (size_t)os[0] * os[1] * os[2];
-  int chunk = std::min(n, 256);
-  if (chunk > stage_chunk) {
-    for (void* p : {(void*)d_x_stage, (void*)d_y_stage, (void*)d_aff}) if (p) HIPCHECK(hipFree(p));
-    d_x_stage = d_y_stage = nullptr; d_aff = nullptr; stage_chunk = 0;
+  // Is the destination page-locked (srcfd_host_alloc, hipHostMalloc / hipHostRegister)?  Then the device-to-host copy of chunk i runs on
+  // a second stream while chunk i + 1 is computed (two result buffers, events both ways) and the whole call moves at the PCIe rate;
+  // into pageable memory the copy is staged by the runtime and nothing overlaps (one buffer, as before).
+  bool pinned = false;
+  if (y && !sink) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, y) == hipSuccess) pinned = at.type == hipMemoryTypeHost;
+    else (void)hipGetLastError();
+  }
+  int chunk = std::min(n, pinned ? 128 : 256);
+  if (chunk > stage_chunk || (pinned && !d_y_stage2)) {
+    chunk = std::max(chunk, stage_chunk);
+    for (void* p : {(void*)d_x_stage, (void*)d_y_stage, (void*)d_y_stage2, (void*)d_aff}) if (p) HIPCHECK(hipFree(p));
+    d_x_stage = d_y_stage = d_y_stage2 = nullptr; d_aff = nullptr; stage_chunk = 0;
+    drop_graph();   // a captured forward holds the old staging addresses
     HIPCHECK(hipMalloc(&d_x_stage, chunk * in_elems * sizeof(float)));
     HIPCHECK(hipMalloc(&d_y_stage, chunk * out_elems * sizeof(float)));
+    if (pinned) HIPCHECK(hipMalloc(&d_y_stage2, chunk * out_elems * sizeof(float)));
     HIPCHECK(hipMalloc(&d_aff, (size_t)chunk * 4 * sizeof(float)));
     stage_chunk = chunk;
   }
+  if (pinned && !copy_stream) {
+    HIPCHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    for (int b = 0; b < 2; ++b) {
+      HIPCHECK(hipEventCreateWithFlags(&ev_computed[b], hipEventDisableTiming));
+      HIPCHECK(hipEventCreateWithFlags(&ev_copied[b], hipEventDisableTiming));
+    }
+  }
   if (!d_nonfinite) HIPCHECK(hipMalloc(&d_nonfinite, sizeof(unsigned long long)));
   HIPCHECK(hipMemsetAsync(d_nonfinite, 0, sizeof(unsigned long long), nullptr));
-  for (int i = 0; i < n; i += stage_chunk) {
-    int c = std::min(stage_chunk, n - i);
+  const int step = pinned ? std::min(stage_chunk, 128) : stage_chunk;
+  int k = 0;
+  for (int i = 0; i < n; i += step, ++k) {
+    int c = std::min(step, n - i);
+    const int b = pinned ? (k & 1) : 0;
+    float* ydev = b ? d_y_stage2 : d_y_stage;
     HIPCHECK(hipMemcpyAsync(d_x_stage, x + (size_t)i * in_elems, c * in_elems * sizeof(float), hipMemcpyHostToDevice, nullptr));
     float* ain = nullptr;
     float* aout = nullptr;
     if (aff_in) { ain = d_aff; HIPCHECK(hipMemcpyAsync(ain, aff_in + 2 * (size_t)i, (size_t)c * 2 * sizeof(float), hipMemcpyHostToDevice, nullptr)); }
     if (aff_out) { aout = d_aff + 2 * (size_t)stage_chunk; HIPCHECK(hipMemcpyAsync(aout, aff_out + 2 * (size_t)i, (size_t)c * 2 * sizeof(float), hipMemcpyHostToDevice, nullptr)); }
-    int rc = predict_device(d_x_stage, c, ain, aout, d_y_stage, SRCFD_F32, flags, d_nonfinite, nullptr);
+    if (pinned && k >= 2) HIPCHECK(hipStreamWaitEvent(nullptr, ev_copied[b], 0));   // the buffer's previous contents have left
+    int rc = predict_device(d_x_stage, c, ain, aout, ydev, SRCFD_F32, flags, d_nonfinite, nullptr);
     if (rc) return rc;
-    if (sink) { rc = sink(d_y_stage, i, c); if (rc) return rc; }
-    else HIPCHECK(hipMemcpyAsync(y + (size_t)i * out_elems, d_y_stage, c * out_elems * sizeof(float), hipMemcpyDeviceToHost, nullptr));
-    HIPCHECK(hipStreamSynchronize(nullptr));
+    if (sink) { rc = sink(ydev, i, c); if (rc) return rc; HIPCHECK(hipStreamSynchronize(nullptr)); }
+    else if (pinned) {
+      HIPCHECK(hipEventRecord(ev_computed[b], nullptr));
+      HIPCHECK(hipStreamWaitEvent(copy_stream, ev_computed[b], 0));
+      HIPCHECK(hipMemcpyAsync(y + (size_t)i * out_elems, ydev, c * out_elems * sizeof(float), hipMemcpyDeviceToHost, copy_stream));
+      HIPCHECK(hipEventRecord(ev_copied[b], copy_stream));
+      // the host arrays of this chunk (x, affines) were consumed by stream-ordered copies from pageable memory: complete on return
+    } else {
+      HIPCHECK(hipMemcpyAsync(y + (size_t)i * out_elems, ydev, c * out_elems * sizeof(float), hipMemcpyDeviceToHost, nullptr));
+      HIPCHECK(hipStreamSynchronize(nullptr));
+    }
   }
+  if (pinned && !sink) { HIPCHECK(hipStreamSynchronize(copy_stream)); HIPCHECK(hipStreamSynchronize(nullptr)); }
   if (n_nonfinite) {
     unsigned long long v = 0;
     HIPCHECK(hipMemcpy(&v, d_nonfinite, sizeof(v), hipMemcpyDeviceToHost));
@@ -694,6 +733,20 @@ int srcfd_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
   return n;
+}
+
+int srcfd_host_alloc(size_t bytes, void** out) {
+  if (!out || bytes == 0) { set_error("srcfd_host_alloc: bad arguments"); return SRCFD_EINVAL; }
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n < 1) { (void)hipGetLastError(); set_error("no HIP device: page-locked memory needs the runtime"); return SRCFD_ENODEV; }
+  hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+  if (e != hipSuccess) { (void)hipGetLastError(); *out = nullptr; set_error(std::string("hipHostMalloc failed: ") + hipGetErrorString(e)); return SRCFD_ENOMEM; }
+  return SRCFD_OK;
+}
+
+void srcfd_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
 }
 
 int srcfd_model_load_h5(const char* encoder_h5, const char* decoder_h5, int device, srcfd_model** out) {

@@ -331,20 +331,18 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
   const uint4* w3_f = reinterpret_cast<const uint4*>(cst + TC_OFF_W3);
   const uint4* w2_f = reinterpret_cast<const uint4*>(p.w2frags);
   const float conv_bias = *reinterpret_cast<const float*>(cst + TC_OFF_BC);
-  const uint4 w4 = reinterpret_cast<const uint4*>(cst + TC_OFF_W4)[lane];  // ConvT#4 operand stays in registers
+  const uint4* const w4_f = reinterpret_cast<const uint4*>(cst + TC_OFF_W4);   // ConvT#4 A operand: read per item (one ds_read_b128)
   // D-item lane constants: tile within the item, window sub-pixel (dy,dx) of this lane's k-group,
   // byte offsets of the five window column pairs relative to granule (plane 0, tx)
-  const int d_tsel = 4 * (lane & 3) + ((lane & 15) >> 2), d_dy = (lane >> 4) & 1, d_dx = lane >> 5;
-  int d_xo[5];
-#pragma unroll
-  for (int cp = 0; cp < 5; ++cp)
-    d_xo[cp] = 16 * (d_dx ? (cp < 4 ? 2 * cp * T_PLANE : 1) : (cp == 0 ? 7 * T_PLANE - 1 : (2 * cp - 1) * T_PLANE));
+  const int d_tsel = 4 * (lane & 3) + ((lane & 15) >> 2);
+  // (window sub-pixel (dy, dx) of a lane's k-group and the five window column offsets of the seam path are recomputed inside do_d:
+  // the hot loop has no register to spare for constants of a path that runs once per sample)
 
   // D fast path (every row pair that is not at a sample / segment seam): everything that depends on the lane only is
   // computed here, once; a round adds wave-uniform terms.  (These address and epilogue instructions were 65 of a D item's
   // vector instructions -- on this chip vector and matrix instructions of a SIMD do not overlap, so they are kernel time.)
   constexpr int OUTSZ = OUT == 0 ? 4 : 2;
-  const int d_rowlane = d_dy * T_ROWP;                               // window row of this lane's k-group, relative to the item's first
+  const int d_rowlane = ((lane >> 4) & 1) * T_ROWP;                  // window row of this lane's k-group, relative to the item's first
   // fast path (operands swapped, below): lane (n = lane & 15, kg = lane >> 4) stores pixels 4 (kg & 1) .. + 3 of row kg >> 1 of tile d_tsel
   const int d_olane = ((lane >> 5) * 400 + 8 * d_tsel + 4 * ((lane >> 4) & 1)) * OUTSZ;   // output byte offset inside the item's row pair
   const bool d_last_on = d_tsel < 2;                                                       // tiles 48, 49: the two that exist in a row pair's fourth item
@@ -374,8 +372,8 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
   for (int i = 0; i < 2; ++i) {
     int tx = 16 * ((d_first + i) & 3) + d_tsel;
     tx = tx < 50 ? tx : 49;
-    d_b0[i] = (tx + 1) * 16 + (d_dx ? 0 : (7 * T_PLANE - 1) * 16);
-    d_b1[i] = (tx + 1) * 16 + (d_dx ? 2 : 1) * T_PLANE * 16;
+    d_b0[i] = (tx + 1) * 16 + ((lane >> 5) ? 0 : (7 * T_PLANE - 1) * 16);
+    d_b1[i] = (tx + 1) * 16 + ((lane >> 5) ? 2 : 1) * T_PLANE * 16;
   }
   unsigned bad_wave = 0;  // non-finite outputs zeroed by the fast path (wave-uniform count)
   // BC item of this wave (bc_item = 2 * pixel tile + ConvT#3 row tile): the lane's 100-level pixel never changes
@@ -489,7 +487,7 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
       acc3 = mfma32<F16>(w3_f[(m3 * 2 + 0) * 64 + lane], b0, acc3);
       acc3 = mfma32<F16>(w3_f[(m3 * 2 + 1) * 64 + lane], b1, acc3);
       uint32_t f3[8];
-      swish_pack16<F16>(acc3, f3, ab_sw);
+      const uint4 w4 = w4_f[lane];
       // the item writes ring rows 8g + 4a + 2 m3 + {0, 1} (a = 100-level row of the lane's pixel; the ConvT#3 tap row is m3
       // for both taps tt): two wave-uniform row offsets per value of a, picked per lane, + the lane's constant granule
       const int rbase = (8 * g) % T_RING_ROWS;
@@ -498,19 +496,38 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
       rb0 = rb0 >= T_RING_ROWS ? rb0 - T_RING_ROWS : rb0; rb1 = rb1 >= T_RING_ROWS ? rb1 - T_RING_ROWS : rb1;
       char* w0 = bc_wbase + (bc_a ? rb0 : ra0) * T_ROWP;
       char* w1 = bc_wbase + (bc_a ? rb1 : ra1) * T_ROWP;
-#pragma unroll
-      for (int tt = 0; tt < 2; ++tt) {
-        uint4 bf = make_uint4(f3[4 * tt], f3[4 * tt + 1], f3[4 * tt + 2], f3[4 * tt + 3]);
-        const f32x16 bias4 = load_bias16(cst + TC_OFF_B4 + h * 64);  // re-read per tap: 16 registers less across the swish
-        f32x16 acc4 = mfma32<F16>(w4, bf, bias4);
-        uint32_t f4[8];
-        swish_pack16<F16>(acc4, f4, ab_sw);
+      // Round 3: ConvT#4's two MFMAs ride INSIDE this wave's own swish stream (tools/microbench9.hip: a v_mfma_f32_32x32x16 between the
+      // transcendentals of the same wave costs the SIMD 3.6 ns, in front of its own swish block and waited for -- round 2 -- 10.7 ns).
+      // Accumulator registers 0-7 of ConvT#3 are tap 0's sixteen channels (k order of w4), 8-15 tap 1's: activate the first half, start
+      // tap 0's MFMA, activate the second half under it, start tap 1's, activate tap 0's result under that.  Same instructions per
+      // element as the round-2 order: bit-identical.
+      f32x16 acc4a, acc4b;
+      if (ab_sw) {       // diagnostic (no swish): the round-2 order
+        swish_pack16<F16>(acc3, f3, true);
+        acc4a = mfma32<F16>(w4, make_uint4(f3[0], f3[1], f3[2], f3[3]), load_bias16(cst + TC_OFF_B4 + h * 64));
+        acc4b = mfma32<F16>(w4, make_uint4(f3[4], f3[5], f3[6], f3[7]), load_bias16(cst + TC_OFF_B4 + h * 64));
+      } else {
+        swish_pack_h<F16, 0, 8>(acc3, f3);
+        pin();
+        acc4a = mfma32<F16>(w4, make_uint4(f3[0], f3[1], f3[2], f3[3]), load_bias16(cst + TC_OFF_B4 + h * 64));
+        pin();
+        swish_pack_h<F16, 8, 8>(acc3, f3 + 4);
+        pin();
+        acc4b = mfma32<F16>(w4, make_uint4(f3[4], f3[5], f3[6], f3[7]), load_bias16(cst + TC_OFF_B4 + h * 64));
+        pin();
+      }
+      auto ring_store = [&](const uint32_t (&f4)[8], const int tt) {
         if (bc_valid) {
 #pragma unroll
           for (int q = 0; q < 4; ++q)   // register pair q: row q >> 1 of the tap's 2x2 block, plane 2 tt + (q & 1)
             *reinterpret_cast<uint2*>(((q >> 1) ? w1 : w0) + (2 * tt + (q & 1)) * (T_PLANE * 16)) = make_uint2(f4[2 * q], f4[2 * q + 1]);
         }
-      }
+      };
+      uint32_t f4[8];
+      swish_pack16<F16>(acc4a, f4, ab_sw);
+      ring_store(f4, 0);
+      swish_pack16<F16>(acc4b, f4, ab_sw);
+      ring_store(f4, 1);
     };
 
     // ---------------- D: output conv of strip g = r-2: tall-image rows 8g-1 .. 8g+6 ----------------
@@ -574,14 +591,20 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
         for (int rr = 0; rr < 4; ++rr) v[rr] = __builtin_fmaf(acc[rr], o_std, o_mean);   // without aff_out: std = 1, mean = 0 -> v exactly
         const bool lane_on = j4 < 3 || d_last_on;   // item 3 of a row pair holds tiles 48, 49 only
         if (p.nan_guard) {
-          unsigned nbad = 0;
+          // ONE question of the four values first (0 * v summed is NaN iff one of them is not finite: 3 fma + 1 multiply + 1 compare);
+          // the per-value zero-fill and count run only then
+          const float t = __builtin_fmaf(v[3], 0.f, __builtin_fmaf(v[2], 0.f, __builtin_fmaf(v[1], 0.f, v[0] * 0.f)));
+          if (__ballot(t != t) != 0ull) {
+            const unsigned long long on = __ballot(lane_on);
+            unsigned nbad = 0;
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            const bool ok = fabsf(v[rr]) <= 3.402823466e38f;
-            nbad += (unsigned)__popcll(__ballot(!ok && lane_on));
-            v[rr] = ok ? v[rr] : 0.f;
+            for (int rr = 0; rr < 4; ++rr) {
+              const bool ok = fabsf(v[rr]) <= 3.402823466e38f;
+              nbad += (unsigned)__popcll(~__ballot(ok) & on);
+              v[rr] = ok ? v[rr] : 0.f;
+            }
+            bad_wave += nbad;
           }
-          bad_wave += nbad;
         }
         if (lane_on) {
           char* o = orow + d_olane;
@@ -598,6 +621,11 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
         const bool seam = emit_prev || emit_top || d_warm;
         if (d_warm && !emit_prev) return;              // flush round / warm-up strip: at most the ended sample's row 399
         const int kg = lane >> 4;
+        const int d_dy = (lane >> 4) & 1, d_dx = lane >> 5;   // window sub-pixel (dy, dx) of this lane's k-group
+        int d_xo[5];                                           // byte offsets of the five window column pairs relative to granule (plane 0, tx)
+#pragma unroll
+        for (int cp = 0; cp < 5; ++cp)
+          d_xo[cp] = 16 * (d_dx ? (cp < 4 ? 2 * cp * T_PLANE : 1) : (cp == 0 ? 7 * T_PLANE - 1 : (2 * cp - 1) * T_PLANE));
         int tx = 16 * j4 + d_tsel;
         tx = tx < 50 ? tx : 49;
         const int sa = (8 * gd + 16 + 2 * rp) % T_RING_ROWS;  // slot of the first window row (tall row 8g-2+2rp)

@@ -109,22 +109,32 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
   // (seen in the ISA; the kernel gained nothing from the prefetch).  As an asm statement the load is outside hipcc's
   // bookkeeping: the stage loop waits for it itself (vmcnt(0) in front of the barrier that publishes the tile).
   const unsigned lds_w0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(msm + C::OFF_W);
+  // Addresses of the staging loads are a wave-uniform base (SGPR pair) + a 32-bit per-lane offset: as 64-bit per-lane pointers (round 2)
+  // the five patch pointers alone took ten registers, hipcc spilled them, and every reload in the loop came with an
+  // s_waitcnt vmcnt(0) that drained the weight tile in flight (seen in the ISA, round 3)
+  unsigned woff[C::WCH];
+#pragma unroll
+  for (int j = 0; j < C::WCH; ++j) {
+    const int r = xrow + RSTEP * j;
+    woff[j] = (unsigned)((r * Kp + ((c8 ^ ((r >> 1) & 7)) * 8)) * 2);
+  }
   auto g2l_w = [&](int t, int c, int buf) {
+    const uint16_t* base = Wt + t * 256 + c * 64;     // wave-uniform
 #pragma unroll
     for (int j = 0; j < C::WCH; ++j) {
-      const int r = xrow + RSTEP * j;
-      const uint16_t* src = Wt + r * Kp + t * 256 + c * 64 + ((c8 ^ ((r >> 1) & 7)) * 8);
       const unsigned dst = __builtin_amdgcn_readfirstlane(lds_w0 + (unsigned)(buf * 16384 + (wave * 64 + C::NTHR * j) * 16));
       unsigned keep;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"(woff[j]), "s"(dst), "s"(base) : "memory");
     }
   };
+  const unsigned poff0 = (unsigned)(xrow * 512 + c8 * 16);   // byte offset of this thread's first patch chunk inside the slab
   auto g2r_p = [&](int c) {
+    const char* base = reinterpret_cast<const char*>(p.in + (size_t)lo * 256 + c * 64);   // wave-uniform
 #pragma unroll
     for (int j = 0; j < C::PCH; ++j) {
       const int r = xrow + RSTEP * j;
-      pr[j] = r < NP ? *reinterpret_cast<const u32x4*>(p.in + (size_t)(lo + r) * 256 + c * 64 + c8 * 8) : u32x4{0, 0, 0, 0};
+      pr[j] = r < NP ? *reinterpret_cast<const u32x4*>(base + (poff0 + (unsigned)(RSTEP * j * 512))) : u32x4{0, 0, 0, 0};
     }
   };
   // ConvT#1's 64 KB of A operands (8 tiles of 8 KB = 512 chunks of 16 B, one per (tap, 32-channel half)) go through the LDS
@@ -140,11 +150,11 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)msm;
 #pragma unroll
     for (int j = 0; j < W1CH; ++j) {
-      const u32x4* src = w1g + half * 2048 + tid + C::NTHR * j;
+      const u32x4* base = w1g + half * 2048 + C::NTHR * j;   // wave-uniform
       const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((wave * 64 + C::NTHR * j) * 16));
       unsigned keep;
-      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep) : "v"((unsigned)(tid * 16)), "s"(dst), "s"(base) : "memory");
     }
   };
   auto r2l_p = [&]() {
@@ -216,25 +226,22 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
     if (tid < 64) reinterpret_cast<float*>(msm + C::OFF_META)[tid] = p.b1f[tid];
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the first operand half has landed
     __syncthreads();
-#pragma unroll 1
-    for (int jj = 0; jj < 8; ++jj) {
-      const int tap = jj >> 1, jh = jj & 1;
-      if (jj == 4) {   // second half: the only point of the stage where the waves meet (its load latency is exposed once)
-        __syncthreads();
-        g2l_w1(1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-      }
-      f32x16 a1 = load_bias16(msm + C::OFF_META + (jh * 2 + h) * 64);
+    // Round 3: software-pipelined by one tile.  The eight MFMAs of tile jj + 1 are issued INSIDE the swish block of tile jj, one after
+    // every four transcendentals of this wave's own stream (dev16.h swish_pack_s; tools/microbench9.hip: an MFMA there costs the SIMD
+    // about its 8 issue cycles instead of its 32), each with its A fragment read from LDS one hook earlier.  Tiles 0 and 4 (the first
+    // of either operand half) are issued in front of the loop / behind the reload.  Same instructions per element: bit-identical.
+    f32x2 one2 = {1.0f, 1.0f};
+    asm volatile("" : "+v"(one2));
+    f32x16 a1[2];
+    auto bfrag = [&](const int s) { return make_uint4(fb[s >> 1][4 * (s & 1)], fb[s >> 1][4 * (s & 1) + 1], fb[s >> 1][4 * (s & 1) + 2], fb[s >> 1][4 * (s & 1) + 3]); };
+    auto issue_tile = [&](const int jj, f32x16& a) {       // all eight MFMAs back to back (nothing to hide them under)
+      a = load_bias16(msm + C::OFF_META + ((jj & 1) * 2 + h) * 64);
       const uint4* wt = w1s + (jj & 3) * 512 + lane;
 #pragma unroll
-      for (int s = 0; s < 8; ++s) {
-        const uint4 wf = wt[s * 64];
-        const uint4 bf = make_uint4(fb[s >> 1][4 * (s & 1)], fb[s >> 1][4 * (s & 1) + 1], fb[s >> 1][4 * (s & 1) + 2], fb[s >> 1][4 * (s & 1) + 3]);
-        a1 = mfma32<F16>(wf, bf, a1);
-      }
-      uint32_t o[8];
-      swish_pack16<F16>(a1, o, MID_ABL(16));
+      for (int s = 0; s < 8; ++s) a = mfma32<F16>(wt[s * 64], bfrag(s), a);
+    };
+    auto tile_out = [&](const int jj, const uint32_t (&o)[8]) {
+      const int tap = jj >> 1, jh = jj & 1;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         *reinterpret_cast<uint2*>(stage + l31 * 144 + 64 * jh + 16 * q + 8 * h) = make_uint2(o[2 * q], o[2 * q + 1]);
@@ -248,6 +255,34 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
           const uint4 v = *reinterpret_cast<const uint4*>(stage + pix * 144 + (lane & 7) * 16);
           if (ob >= 0 && !MID_ABL(8)) *reinterpret_cast<uint4*>(p.out + ob + toff + (lane & 7) * 8) = v;
         }
+      }
+    };
+    issue_tile(0, a1[0]);
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      uint32_t o[8];
+      constexpr int dummy = 0; (void)dummy;
+      if (jj + 1 < 8 && jj + 1 != 4 && !MID_ABL(16)) {
+        f32x16& an = a1[(jj + 1) & 1];
+        an = load_bias16(msm + C::OFF_META + (((jj + 1) & 1) * 2 + h) * 64);
+        const uint4* wt = w1s + ((jj + 1) & 3) * 512 + lane;
+        uint4 wf = wt[0];
+        swish_pack_s<F16, 0, 16>(a1[jj & 1], o, one2, [&](auto k) {
+          constexpr int S = decltype(k)::value;
+          an = mfma32<F16>(wf, bfrag(S), an);
+          if constexpr (S < 7) wf = wt[(S + 1) * 64];      // the next fragment, into the register the MFMA has just read
+        });
+      } else {
+        swish_pack16<F16>(a1[jj & 1], o, MID_ABL(16));
+        if (jj + 1 < 8 && jj + 1 != 4) issue_tile(jj + 1, a1[(jj + 1) & 1]);   // (diagnostic no-swish build)
+      }
+      tile_out(jj, o);
+      if (jj == 3) {   // second half of the operands: the only point of the stage where the waves meet (its load latency is exposed once)
+        __syncthreads();
+        g2l_w1(1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        issue_tile(4, a1[0]);
       }
     }
   }

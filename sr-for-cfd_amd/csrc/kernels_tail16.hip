@@ -34,7 +34,6 @@
 
 namespace srcfd {
 
-template <int K> using ic = std::integral_constant<int, K>;
 
 // Diagnostic work-skipping switches (TailParams::ablate, SRCFD_TAIL_ABLATE) exist only in a -DSRCFD_DIAG build (make DIAG=1): the
 // shipped kernel carries no path that turns work off.  tail16s: 1 Y: no input prefetch, 2 Y: no deferred store, 4 Y: no D item,
@@ -44,48 +43,6 @@ template <int K> using ic = std::integral_constant<int, K>;
 #else
 #define TS_ABL(bit) 0
 #endif
-
-// swish + pack over NR (8 or 16) accumulator registers starting at R0; hook(ic<k>) after every four transcendentals
-// (k = 0 .. NR/2 - 1: first the exps, then the rcps).  Same instructions per element as swish_pack16 (dev16.h): bit-identical.
-template <bool F16, int R0, int NR, class H>
-__device__ __forceinline__ void swish_pack_s(const f32x16& dd, uint32_t* o, const f32x2& one2, H&& hook) {   // one2 = {1, 1}, kept in a register pair by the caller (hipcc otherwise rebuilds it from scalars in front of every block)
-  constexpr int NP = NR / 2, NG = NP / 2;
-  f32x2 u2[NP], e2[NP];
-#pragma unroll
-  for (int i = 0; i < NP; ++i) u2[i] = f32x2{dd[R0 + 2 * i], dd[R0 + 2 * i + 1]};
-  auto exps = [&](auto g) {
-    constexpr int G = decltype(g)::value;
-#pragma unroll
-    for (int i = 2 * G; i < 2 * G + 2; ++i) {
-      e2[i].x = __builtin_amdgcn_exp2f(-u2[i].x);
-      e2[i].y = __builtin_amdgcn_exp2f(-u2[i].y);
-    }
-    pin();
-    hook(ic<G>());
-    pin();
-  };
-  auto rcps = [&](auto g) {
-    constexpr int G = decltype(g)::value;
-#pragma unroll
-    for (int i = 2 * G; i < 2 * G + 2; ++i) {
-      asm volatile("v_rcp_f32 %0, %0" : "+v"(e2[i].x));
-      asm volatile("v_rcp_f32 %0, %0" : "+v"(e2[i].y));
-    }
-    pin();
-    hook(ic<NG + G>());
-    pin();
-  };
-  exps(ic<0>()); exps(ic<1>());
-  if constexpr (NG == 4) { exps(ic<2>()); exps(ic<3>()); }
-#pragma unroll
-  for (int i = 0; i < NP; ++i) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(e2[i]) : "v"(one2));
-  rcps(ic<0>()); rcps(ic<1>());
-  if constexpr (NG == 4) { rcps(ic<2>()); rcps(ic<3>()); }
-#pragma unroll
-  for (int i = 0; i < NP; ++i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(e2[i]) : "v"(u2[i]));
-#pragma unroll
-  for (int i = 0; i < NP; ++i) o[i] = pack2<F16>(e2[i].x, e2[i].y);
-}
 
 template <bool F16, int OUT, bool SEG, bool PROF = false>  // OUT: 0 f32, 1 bf16, 2 f16; SEG: samples cut into segments (small batches); PROF: per-wave round timers (DIAG builds)
 __global__ void __launch_bounds__(512) tail16s(TailParams p) {

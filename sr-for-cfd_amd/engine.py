@@ -8,6 +8,7 @@ replaces what ``tf.keras.models.load_model`` + ``SuperResolutionAE`` +
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -48,6 +49,64 @@ def layers_from_weights(enc_w: Optional[Dict[str, np.ndarray]], dec_w: Optional[
         specs.append(dict(kind="conv2d", name="output_image_400", k=3, stride=1, same=True, act="linear",
                           w=dec_w["output_image_400/kernel"], b=dec_w["output_image_400/bias"]))
     return specs
+
+
+class _PinnedPool:
+    """Recycling pool of page-locked result buffers (srcfd_host_alloc).  `empty(shape)` returns a float32 ndarray over a pool buffer;
+    the buffer goes back to the pool when the array and every view of it are gone (a weakref finalizer on the ctypes object all
+    the views hang from).  Bounded: at most `cap_bytes` are kept for reuse, the rest is freed.  Small results (< `min_bytes`) and
+    hosts where the allocation fails use ordinary numpy memory.  SRCFD_RESULT_POOL=0 switches the pool off."""
+
+    def __init__(self, min_bytes: int = 4 << 20, cap_bytes: int = 4 << 30):
+        import threading
+        self.min_bytes, self.cap_bytes = min_bytes, cap_bytes
+        self.free = {}            # nbytes -> [ptr, ...]
+        self.cached = 0
+        self.lock = threading.Lock()
+        self.enabled = os.environ.get("SRCFD_RESULT_POOL", "1") not in ("0", "")
+        self.stats = {"allocated": 0, "reused": 0, "fallback": 0}
+
+    def _release(self, ptr: int, nbytes: int) -> None:
+        with self.lock:
+            if self.cached + nbytes <= self.cap_bytes:
+                self.free.setdefault(nbytes, []).append(ptr)
+                self.cached += nbytes
+                return
+        L.lib.srcfd_host_free(C.c_void_p(ptr))
+
+    def empty(self, shape) -> np.ndarray:
+        import weakref
+        nbytes = int(np.prod(shape)) * 4
+        if not self.enabled or nbytes < self.min_bytes:
+            return np.empty(shape, dtype=np.float32)
+        ptr = None
+        with self.lock:
+            lst = self.free.get(nbytes)
+            if lst:
+                ptr = lst.pop()
+                self.cached -= nbytes
+                self.stats["reused"] += 1
+        if ptr is None:
+            out = C.c_void_p()
+            if L.lib.srcfd_host_alloc(nbytes, C.byref(out)) != 0 or not out.value:
+                self.stats["fallback"] += 1
+                return np.empty(shape, dtype=np.float32)
+            ptr = out.value
+            self.stats["allocated"] += 1
+        buf = (C.c_char * nbytes).from_address(ptr)
+        weakref.finalize(buf, self._release, ptr, nbytes)
+        return np.frombuffer(buf, dtype=np.float32).reshape(shape)
+
+    def trim(self) -> None:
+        """Frees every cached buffer (buffers still referenced by arrays stay alive until those die)."""
+        with self.lock:
+            items, self.free, self.cached = self.free, {}, 0
+        for lst in items.values():
+            for ptr in lst:
+                L.lib.srcfd_host_free(C.c_void_p(ptr))
+
+
+_result_pool = _PinnedPool()
 
 
 class SRModel:
@@ -219,7 +278,10 @@ class SRModel:
         n = x.shape[0]
         oh, ow, oc = self.output_shape
         if out is None:
-            y = np.empty((n, oh, ow, oc), dtype=np.float32)
+            # a result of this size moves at the PCIe rate only into page-locked memory, and a FRESH pageable array pays more in
+            # first-touch page faults than in transfer time: large results come from a recycling pool of page-locked buffers
+            # (returned to it when the last view of the array dies); `Model.predict` still hands back a new ndarray every call
+            y = _result_pool.empty((n, oh, ow, oc)) if self.device >= 0 else np.empty((n, oh, ow, oc), dtype=np.float32)
         else:
             if out.shape != (n, oh, ow, oc) or out.dtype != np.float32 or not out.flags.c_contiguous:
                 raise ValueError(f"out must be a C-contiguous float32 array of shape {(n, oh, ow, oc)}")

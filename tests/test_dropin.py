@@ -346,6 +346,55 @@ def test_device_statistics_follow_numpy_beyond_128_elements(srcfd, side):
 
 
 @pytest.mark.gpu
+def test_large_results_come_from_the_page_locked_pool(srcfd, enc_weights, dec_weights):
+    """`predict` returns a NEW array per call (the reference's contract, PyCFD_ML_accelerated.py:858); large ones live in recycled
+    page-locked buffers: the values equal the `out=` path's, a buffer returns to the pool only when the array AND its views are gone
+    (a field sliced out of a result keeps it alive), the next call of the same size reuses it, and small results are plain numpy."""
+    import gc
+    import importlib
+    require_gpu(srcfd)
+    eng = importlib.import_module("sr-for-cfd_amd.engine")
+    pool = eng._result_pool
+    rng = np.random.default_rng(4)
+    n = 40                                                  # 40 x 640 kB = 25.6 MB: above the pool's 4 MB threshold, two chunks? no: one
+    x = rng.standard_normal((n, 10, 10, 1)).astype(np.float32)
+    m = srcfd.SRModel.from_weights(enc_weights, dec_weights, device=0)
+    m.precision = "bf16"
+    ref = np.empty((n, 400, 400, 1), np.float32)
+    m.predict(x, out=ref)
+    before = dict(pool.stats)
+    y = m.predict(x)
+    assert pool.stats["allocated"] + pool.stats["reused"] == before["allocated"] + before["reused"] + 1
+    np.testing.assert_array_equal(y, ref)
+    addr = y.ctypes.data
+    field = y[3, ..., 0]                                    # what the solver harness keeps
+    del y
+    gc.collect()
+    y2 = m.predict(x)                                       # the first buffer is still referenced by `field`: a different one
+    assert y2.ctypes.data != addr
+    np.testing.assert_array_equal(field, ref[3, ..., 0])
+    del field, y2
+    gc.collect()
+    reused = pool.stats["reused"]
+    y3 = m.predict(x)
+    assert pool.stats["reused"] == reused + 1               # recycled, no new page-locked allocation
+    np.testing.assert_array_equal(y3, ref)
+    small = m.predict(x[:2])                                # 1.3 MB: ordinary numpy memory
+    np.testing.assert_array_equal(small, ref[:2])
+    # a batch of several chunks through the overlapped copy path (> 128 samples), against the single-buffer path into pageable memory
+    xb = rng.standard_normal((300, 10, 10, 1)).astype(np.float32)
+    aout = np.stack([rng.standard_normal(300) * 0.1, rng.uniform(0.05, 0.3, 300)], 1).astype(np.float32)
+    refb = np.empty((300, 400, 400, 1), np.float32)
+    m.predict(xb, out_affine=aout, nan_guard=True, out=refb)
+    yb, bad = m.predict(xb, out_affine=aout, nan_guard=True, return_nonfinite=True)
+    np.testing.assert_array_equal(yb, refb)
+    assert bad == 0
+    del y3, yb
+    gc.collect()
+    pool.trim()
+
+
+@pytest.mark.gpu
 def test_verbose_call_prints_the_reference_style_report_and_same_fields(srcfd, decoder_h5, coarse_cases, capsys):
     """verbose=True reports the blended statistics and the range of every component (the reference prints them on every
     call, bfs_ml_accelerated.py:1096-1145); the quiet default skips those range scans but returns the same arrays."""
