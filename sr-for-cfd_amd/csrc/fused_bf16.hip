@@ -433,8 +433,14 @@ int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, cons
       mp.w1f = P.d_w1f;
       mp.b1f = P.d_midb + 128;
       mp.ablate = 0;
+      mp.prof = nullptr;
 #ifdef SRCFD_DIAG
       { static const int abl = [] { const char* e = getenv("SRCFD_MID_ABLATE"); return e ? atoi(e) : 0; }(); mp.ablate = abl; }
+      static unsigned long long* d_mprof = nullptr;   // SRCFD_MID_PROF=1: section cycle sums of wave 0 of every workgroup, per output phase
+      static int mprof_calls = 0;
+      static const bool mprof = getenv("SRCFD_MID_PROF") != nullptr;
+      if (mprof && !d_mprof) { HIPCHECK(hipMalloc(&d_mprof, 24 * sizeof(unsigned long long))); }
+      if (mprof) { HIPCHECK(hipMemsetAsync(d_mprof, 0, 24 * sizeof(unsigned long long), s)); mp.prof = d_mprof; }
 #endif
       static const int mid_waves = [] {  // read once; anything but 4 / 8 / 16 waves per workgroup is ignored
         const char* e = getenv("SRCFD_MID_WAVES");
@@ -443,6 +449,19 @@ int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, cons
       }();
       rc = m.launch("mid(convT0+convT1)", s, [&] { return launch_mid16(f16, mp, mid_waves, s); });
       if (rc) return rc;
+#ifdef SRCFD_DIAG
+      if (mprof && ++mprof_calls == 20) {
+        unsigned long long hb[24];
+        HIPCHECK(hipStreamSynchronize(s));
+        HIPCHECK(hipMemcpy(hb, d_mprof, sizeof(hb), hipMemcpyDeviceToHost));
+        fprintf(stderr, "mid16, wave 0 of every workgroup, mean cycles per workgroup by output phase: workgroups | entry->tables | ->first stage ready | main loop | ConvT#0 swish | ConvT#1 stage\n");
+        for (int ph = 0; ph < 4; ++ph) {
+          const double nwg = (double)std::max<unsigned long long>(hb[ph * 6], 1);
+          fprintf(stderr, "  phase %d: %6llu | %7.0f | %7.0f | %7.0f | %7.0f | %7.0f\n", ph, hb[ph * 6], hb[ph * 6 + 1] / nwg, hb[ph * 6 + 2] / nwg, hb[ph * 6 + 3] / nwg,
+                  hb[ph * 6 + 4] / nwg, hb[ph * 6 + 5] / nwg);
+        }
+      }
+#endif
     }
     cur ^= 1;
     fs->t1_buf = cur;

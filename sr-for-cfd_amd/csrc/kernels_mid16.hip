@@ -59,6 +59,13 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
   const int phase = blockIdx.y, blk = blockIdx.x;
+#ifdef SRCFD_DIAG
+  unsigned long long tstamp[6];
+  tstamp[0] = __builtin_amdgcn_s_memtime();
+#define MID_STAMP(i) do { if (p.prof) { __builtin_amdgcn_sched_barrier(0); tstamp[i] = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#else
+#define MID_STAMP(i) do { } while (0)
+#endif
   const int py = phase >> 1, px = phase & 1;
   const int TY = py ? 1 : 2, TX = px ? 1 : 2, NT = TY * TX;
   const int MH = py ? 12 : 13, MW = px ? 12 : 13, per = MH * MW;
@@ -75,6 +82,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
   if (tid < M_PITCH / 2) reinterpret_cast<uint32_t*>(Ps + C::PATCH * M_PITCH)[tid] = 0;
   __syncthreads();
 
+  MID_STAMP(1);
   // contiguous slab of input pixels (tensor index img*144 + iy*12 + ix) this workgroup touches
   const int mlast = min(m0 + C::PX - 1, M - 1) - m0;
   const int lo = row_img[0] * 144 + max(row_my[0] - 1, 0) * 12;
@@ -183,6 +191,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile s (asm global_load_lds, issued a stage ago) has landed in this wave's share
     __syncthreads();   // ... and in everybody's; the patch is visible
+    if (s == 0) MID_STAMP(2);
     if (s + 1 < NS && !MID_ABL(4)) {
       const int c1 = (s + 1) / NT, t1 = (s + 1) - c1 * NT;
       if (t1 == 0) g2r_p(c1);
@@ -203,6 +212,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
     }
   }
   __syncthreads();   // the ConvT#1 stage re-uses the patch and weight space
+  MID_STAMP(3);
 
   // ---- ConvT#0 epilogue: swish, pack; the packed accumulators are ConvT#1's B operands ----
   // ConvT#1's first operand half is in flight during the swish below
@@ -211,6 +221,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt) swish_pack16<F16>(acc[mt], fb[mt]);
 
+  MID_STAMP(4);
   // ---- ConvT#1: 8 tiles of 32 rows (tap = j8 >> 1, channels 32*(j8&1)..+31), K = 128 = 8 k-steps.
   // Its 64 KB of A operands go through the (now free) LDS one 8 KB tile at a time (double-buffered), shared by all waves.
   // Each tap's 32 pixels x 64 channels are transposed through a wave-private LDS tile so that the
@@ -286,6 +297,17 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
       }
     }
   }
+#ifdef SRCFD_DIAG
+  if (p.prof && tid == 0) {
+    const unsigned long long t5 = __builtin_amdgcn_s_memtime();
+    atomicAdd(p.prof + phase * 6 + 0, 1ull);
+    atomicAdd(p.prof + phase * 6 + 1, tstamp[1] - tstamp[0]);
+    atomicAdd(p.prof + phase * 6 + 2, tstamp[2] - tstamp[1]);
+    atomicAdd(p.prof + phase * 6 + 3, tstamp[3] - tstamp[2]);
+    atomicAdd(p.prof + phase * 6 + 4, tstamp[4] - tstamp[3]);
+    atomicAdd(p.prof + phase * 6 + 5, t5 - tstamp[4]);
+  }
+#endif
 }
 
 template <bool F16, int NW>
