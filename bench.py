@@ -48,7 +48,7 @@ MACS_PER_SAMPLE = 140_024_128
 PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16/f16 MFMA (MI355X_MICROARCH.md)
 PEAK_FP32_TFLOPS = 157.3          # f32-input MFMA
 PEAK_HBM_GBS = 8000.0
-PRE_WARM_MS = 80.0                # untimed steps by wall time in front of the counted warm-up of an SR leg (clock ramp; Job.timed)
+PRE_WARM_MS = 120.0               # untimed steps by wall time in front of the counted warm-up of an SR leg (clock ramp; Job.timed)
 REFUSED_ENV = ("SRCFD_TAIL_ABLATE", "SRCFD_MID_ABLATE", "SRCFD_TAIL_PROF")   # switch work off / add syncs: never a headline
 # A/B switches: each selects a complete second implementation of a stage (results stay right), but a line measured under one is
 # not the shipped path: refused like the diagnostic switches (SRCFD_BENCH_ALLOW_DIAG=1 marks the line INVALID instead)
@@ -389,18 +389,20 @@ class Job:
                 fl = tail_flops(self.n)
                 ach = fl / (kernels[dom] * 1e-3) / 1e12
                 traffic, traffic_src = measured_traffic(args.fields, precision, out_dtype)
-                floor = self.n * 2_240_000 / 64 * 23.6 / 1024 / 2.4e9 * 1e3
+                # 2 240 000 swish activations per sample in this kernel; 9.58 ns of SIMD time per 64 of them incl. the 16-bit pack
+                # (profiles/r03/a_microbench9...: the kernel's own instruction mix, 4 waves per SIMD, wall time), 1024 SIMDs
+                floor = self.n * 2_240_000 / 64 * 9.58e-9 / 1024 * 1e3
                 rec["roofline"] = {
                     "bound": "mfma", "kernel": dom, "achieved": round(ach, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes/launch (HBM, PMC)",
                     "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": self.n * 160000 * (2 + (4 if out_dtype == "f32" else 2)),
                     "avg_launch_ms": kernels[dom], "algorithmic_flops_per_launch": fl,
-                    # what actually binds (not expressible as "hbm" | "mfma"): 2 240 000 swish activations per sample in this
-                    # kernel at the measured 23.6 SIMD-cycles per 64 (profiles/r01/microbench6_valu_throughput.txt), 1024 SIMDs, 2.4 GHz
+                    # what actually binds (not expressible as "hbm" | "mfma"): the vector unit's swish stream
                     "valu_swish_floor_ms": round(floor, 4), "frac_of_valu_swish_floor": round(floor / kernels[dom], 4),
-                    "note": "swish = 2 quarter-rate transcendentals per activation: exact swish caps this network at ~0.28 of the MFMA "
-                            "peak on the VALU transcendental rate (DESIGN.md 4.2)"}
+                    "note": "swish = 2 transcendentals per activation: exact swish caps this network at ~0.28 of the MFMA peak on the "
+                            "vector unit (DESIGN.md 4.2); bf16 MFMAs hide under the swish stream of the wave that issues them, not under "
+                            "another wave's (DESIGN.md 4.2b, profiles/r03/a_microbench9...)"}
             else:
                 # whole f32 step: all 768 samples' FLOPs over the SUM of every launch of the step (all chunks)
                 fl = 2.0 * MACS_PER_SAMPLE * self.n
@@ -413,8 +415,9 @@ class Job:
                                    "traffic_unit": "bytes/step (HBM, PMC)", "traffic_source": traffic_src,
                                    "algorithmic_bytes_per_launch": self.n * (100 + 160000) * 4,
                                    "avg_launch_ms": round(tot, 4), "algorithmic_flops_per_launch": fl,
-                                   "note": "f32 MFMAs and vector instructions of a SIMD do not overlap on gfx950 (profiles/r02/d_microbench8...): "
-                                           "the swish / output-conv vector work of this path is paid on top of the MFMA time"}
+                                   "note": "f32-input MFMAs and vector instructions of a SIMD do not overlap on gfx950, neither across waves nor in one "
+                                           "wave's stream (profiles/r02/d_microbench8...): the swish / output-conv vector work of this path is paid on "
+                                           "top of the MFMA time (the 16-bit MFMAs differ: DESIGN.md 4.2b)"}
         return rec, y
 
     # -- config 4: training step ---------------------------------------------------------------------------------
