@@ -52,7 +52,8 @@ PRE_WARM_MS = 120.0               # untimed steps by wall time in front of the c
 REFUSED_ENV = ("SRCFD_TAIL_ABLATE", "SRCFD_MID_ABLATE", "SRCFD_TAIL_PROF")   # switch work off / add syncs: never a headline
 # A/B switches: each selects a complete second implementation of a stage (results stay right), but a line measured under one is
 # not the shipped path: refused like the diagnostic switches (SRCFD_BENCH_ALLOW_DIAG=1 marks the line INVALID instead)
-AB_ENV_OFF_WHEN_ZERO = ("SRCFD_ENC", "SRCFD_MID", "SRCFD_DENSE1")
+AB_ENV_OFF_WHEN_ZERO = ("SRCFD_ENC", "SRCFD_DENSE1")
+AB_ENV_DEFAULT_VALUE = {"SRCFD_MID": "2"}    # 2 = mid16 with 512-pixel workgroups (shipped); 1 = 256-pixel workgroups; 0 = generic GEMMs
 AB_ENV_ON_WHEN_SET = ("SRCFD_NO_ENC32", "SRCFD_NO_DENSE_SKINNY", "SRCFD_NO_TAIL32", "SRCFD_NO_GEMM32_BIG", "SRCFD_NO_PAIR", "SRCFD_NO_TRIPLE")
 AB_ENV_ANY_VALUE = ("SRCFD_TAIL", "SRCFD_TAIL_SEG", "SRCFD_MID_WAVES", "SRCFD_GRAPH", "SRCFD_LIB", "SRCFD_TRAIN_OVERLAP", "SRCFD_TRAIN_GRAPH",
                     "SRCFD_TRAIN_FUSE")
@@ -66,6 +67,7 @@ def non_default_switches(env):
     """SRCFD_* variables that change WHICH kernels run (diagnostic or A/B): a headline line is never reported under them."""
     bad = [k for k in env if k in REFUSED_ENV and env[k] not in ("", "0")]
     bad += [k for k in AB_ENV_OFF_WHEN_ZERO if k in env and env[k].strip() == "0"]
+    bad += [k for k, dflt in AB_ENV_DEFAULT_VALUE.items() if env.get(k, "").strip() not in ("", dflt)]
     bad += [k for k in AB_ENV_ON_WHEN_SET if env.get(k, "") not in ("", "0")]
     bad += [k for k in AB_ENV_ANY_VALUE if env.get(k, "") != ""]
     return bad

@@ -300,6 +300,7 @@ Switches Switches::from_env() {
   Switches w;
   w.enc16 = on("SRCFD_ENC", true);
   w.mid16 = on("SRCFD_MID", true);
+  { const char* e = getenv("SRCFD_MID"); if (e && atoi(e) != 0) w.mid_wide = atoi(e) == 2; }
   w.dense1_16 = on("SRCFD_DENSE1", true);
   w.enc32 = !on("SRCFD_NO_ENC32", false);
   w.skinny32 = !on("SRCFD_NO_DENSE_SKINNY", false);
@@ -951,7 +952,7 @@ int srcfd_model_last_plan(const srcfd_model* m, char* buf, size_t buf_len) {
   char tmp[256];
   if (p.fused)
     snprintf(tmp, sizeof(tmp), "precision=%s encoder=%s dense_1=%s middle=%s tail=%s tail_seg=%d graph=%s", prec, p.sw.enc16 ? "enc16" : "layers",
-             p.sw.dense1_16 ? "dense1_16" : "gemm16", p.sw.mid16 ? "mid16" : "gemm16", p.sw.tail16s ? "tail16s" : "tail16", p.tail_seg,
+             p.sw.dense1_16 ? "dense1_16" : "gemm16", p.sw.mid16 ? (p.sw.mid_wide ? "mid16w" : "mid16") : "gemm16", p.sw.tail16s ? "tail16s" : "tail16", p.tail_seg,
              p.graph == 2 ? "replay" : p.graph == 1 ? "capture" : "eager");
   else
     snprintf(tmp, sizeof(tmp), "precision=%s encoder=%s dense_1=%s graph=%s", prec, p.sw.enc32 ? "enc32" : "layers",

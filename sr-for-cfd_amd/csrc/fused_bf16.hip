@@ -57,6 +57,8 @@ struct Pack16 {  // one per operand type (bf16, f16)
   void* d_consts = nullptr;
   void* d_w2f = nullptr;
   void* d_w1f = nullptr;   // mid16: ConvT#1 operands
+  uint16_t* d_w0t = nullptr;   // mid16: ConvT#0 weights as the 16 KB LDS images of its stages, per output phase (offsets in w0t_off)
+  size_t w0t_off[4] = {0, 0, 0, 0};
   void* d_encf = nullptr;  // enc16: conv2d_1, dense, latent_vector operand fragments (one blob)
   size_t enc_wd_off = 0, enc_wl_off = 0;  // byte offsets of the dense / latent fragments in d_encf
   float* d_encb = nullptr; // enc16: conv2d_1 bias fragments (128 floats)
@@ -277,6 +279,32 @@ static int build_pack(Model& m, FusedState* fs, bool f16) {
             w1[(((size_t)j8 * 8 + st) * 64 + l) * 8 + j] = to16(L1.kernel[((size_t)tap * 64 + co) * 128 + ci], f16);
           }
         }
+    // ConvT#0 weights, stage by stage, in the order the kernel's LDS tile holds them: stage (chunk c, tap t) of a phase = [128 rows][64 k]
+    // = 1024 sixteen-byte pieces, piece row * 8 + slot holding k-piece slot ^ ((row >> 1) & 7) (the bank swizzle of the fragment reads).
+    // A tile is then 16 KB of CONSECUTIVE memory.  Read from the GEMM layout Wt[128][Kpad] instead, its 128 row segments lie Kpad * 2 =
+    // 512 / 1024 / 2048 bytes apart -- powers of two: every workgroup of a phase asks the same one or two L2 channels for the same tile
+    // at the same time (round 3: the tile loads' cost did not hide behind anything, whatever the prefetch depth).
+    {
+      std::vector<uint16_t> wt;
+      int ph = 0;
+      for (const Op16& o : fs->ops) {
+        if (o.layer != 5 || ph >= 4) continue;
+        const int NT = o.d.K / 256;
+        P.w0t_off[ph++] = wt.size();
+        const uint16_t* W = w.data() + o.w_off;
+        for (int st = 0; st < 4 * NT; ++st) {
+          const int c = st / NT, t = st - c * NT;
+          for (int i = 0; i < 1024; ++i) {
+            const int row = i >> 3, kc = (i & 7) ^ ((row >> 1) & 7);
+            for (int j = 0; j < 8; ++j) wt.push_back(W[(size_t)row * o.Kpad + t * 256 + c * 64 + kc * 8 + j]);
+          }
+        }
+      }
+      if (!wt.empty()) {
+        HIPCHECK(hipMalloc(&P.d_w0t, wt.size() * sizeof(uint16_t)));
+        HIPCHECK(hipMemcpy(P.d_w0t, wt.data(), wt.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+      }
+    }
     HIPCHECK(hipMalloc(&P.d_w1f, w1.size() * sizeof(uint16_t)));
     HIPCHECK(hipMemcpy(P.d_w1f, w1.data(), w1.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
     std::vector<float> mb(128 + 64);
@@ -301,6 +329,7 @@ void fused_free(Model& m) {
     if (P.d_consts) (void)hipFree(P.d_consts);
     if (P.d_w2f) (void)hipFree(P.d_w2f);
     if (P.d_w1f) (void)hipFree(P.d_w1f);
+    if (P.d_w0t) (void)hipFree(P.d_w0t);
     if (P.d_midb) (void)hipFree(P.d_midb);
     if (P.d_encf) (void)hipFree(P.d_encf);
     if (P.d_encb) (void)hipFree(P.d_encb);
@@ -428,7 +457,7 @@ int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, cons
       mp.n = c;
       int ph = 0;
       for (const Op16& o : fs->ops)
-        if (o.layer == 5) { mp.w0[ph] = P.d_w + o.w_off; mp.kpad[ph] = o.Kpad; ++ph; }
+        if (o.layer == 5) { mp.w0[ph] = P.d_w + o.w_off; mp.kpad[ph] = o.Kpad; mp.w0t[ph] = P.d_w0t + P.w0t_off[ph]; ++ph; }
       mp.b0f = P.d_midb;
       mp.w1f = P.d_w1f;
       mp.b1f = P.d_midb + 128;
@@ -439,27 +468,29 @@ int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, cons
       static unsigned long long* d_mprof = nullptr;   // SRCFD_MID_PROF=1: section cycle sums of wave 0 of every workgroup, per output phase
       static int mprof_calls = 0;
       static const bool mprof = getenv("SRCFD_MID_PROF") != nullptr;
-      if (mprof && !d_mprof) { HIPCHECK(hipMalloc(&d_mprof, 24 * sizeof(unsigned long long))); }
-      if (mprof) { HIPCHECK(hipMemsetAsync(d_mprof, 0, 24 * sizeof(unsigned long long), s)); mp.prof = d_mprof; }
+      if (mprof && !d_mprof) { HIPCHECK(hipMalloc(&d_mprof, 60 * sizeof(unsigned long long))); }
+      if (mprof) { HIPCHECK(hipMemsetAsync(d_mprof, 0, 60 * sizeof(unsigned long long), s)); mp.prof = d_mprof; }
 #endif
       static const int mid_waves = [] {  // read once; anything but 4 / 8 / 16 waves per workgroup is ignored
         const char* e = getenv("SRCFD_MID_WAVES");
         const int v = e ? atoi(e) : 8;
         return (v == 4 || v == 8 || v == 16) ? v : 8;
       }();
-      rc = m.launch("mid(convT0+convT1)", s, [&] { return launch_mid16(f16, mp, mid_waves, s); });
+      rc = m.launch("mid(convT0+convT1)", s, [&] { return launch_mid16(f16, mp, m.sw.mid_wide ? 82 : mid_waves, s); });
       if (rc) return rc;
 #ifdef SRCFD_DIAG
       if (mprof && ++mprof_calls == 20) {
-        unsigned long long hb[24];
+        unsigned long long hb[60];
         HIPCHECK(hipStreamSynchronize(s));
         HIPCHECK(hipMemcpy(hb, d_mprof, sizeof(hb), hipMemcpyDeviceToHost));
         fprintf(stderr, "mid16, wave 0 of every workgroup, mean cycles per workgroup by output phase: workgroups | entry->tables | ->first stage ready | main loop | ConvT#0 swish | ConvT#1 stage\n");
         for (int ph = 0; ph < 4; ++ph) {
           const double nwg = (double)std::max<unsigned long long>(hb[ph * 6], 1);
-          fprintf(stderr, "  phase %d: %6llu | %7.0f | %7.0f | %7.0f | %7.0f | %7.0f\n", ph, hb[ph * 6], hb[ph * 6 + 1] / nwg, hb[ph * 6 + 2] / nwg, hb[ph * 6 + 3] / nwg,
-                  hb[ph * 6 + 4] / nwg, hb[ph * 6 + 5] / nwg);
+          fprintf(stderr, "  phase %d: %6llu | %7.0f | %7.0f | %7.0f | %7.0f | %7.0f    main loop = sync %7.0f + issue %7.0f + fragments/MFMA %7.0f\n", ph, hb[ph * 6], hb[ph * 6 + 1] / nwg, hb[ph * 6 + 2] / nwg, hb[ph * 6 + 3] / nwg,
+                  hb[ph * 6 + 4] / nwg, hb[ph * 6 + 5] / nwg, hb[24 + ph * 3] / nwg, hb[24 + ph * 3 + 1] / nwg, hb[24 + ph * 3 + 2] / nwg);
         }
+        fprintf(stderr, "  workgroup 3 of phase 0, per wave, main loop: sync | issue | fragments/MFMA\n");
+        for (int w = 0; w < 8; ++w) fprintf(stderr, "    wave %d: %7llu | %7llu | %7llu\n", w, hb[36 + w * 3], hb[36 + w * 3 + 1], hb[36 + w * 3 + 2]);
       }
 #endif
     }

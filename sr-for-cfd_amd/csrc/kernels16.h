@@ -56,6 +56,7 @@ struct MidParams {
   int n;
   const uint16_t* w0[4];   // per output phase (py*2+px): ConvT#0 weights [128 ch][kpad], k = tap*256 + ci
   int kpad[4];
+  const uint16_t* w0t[4];  // the same weights as the LDS images of the kernel's stages: [stage c * taps + t][1024 pieces of 16 B] (fused_bf16.hip)
   const float* b0f;        // ConvT#0 bias as accumulator init [m-tile 4][lane half 2][16]
   const void* w1f;         // ConvT#1 A operands [m-tile 8][k-step 8][64 lanes] x 16 B, k in accumulator order
   const float* b1f;        // ConvT#1 bias as accumulator init [channel half 2][lane half 2][16]

@@ -31,25 +31,33 @@ constexpr int M_PITCH = 72;  // LDS row pitch in elements (144 B)
 // NW waves per workgroup, each owning 32 output pixels x 128 channels.  The weight tile (16 KB per
 // stage) is shared by all NW waves, so bytes pulled through L2 per output pixel fall as 1/NW:
 // with 4 waves this kernel sat at ~17 GB/s per CU of operand traffic (the per-CU load rate), not on the MFMAs.
-template <int NW> struct MidCfg {
-  static constexpr int PX = 32 * NW;                    // output pixels per workgroup
+// PT pixel tiles per wave: 1 = two workgroups of 256 pixels per CU (128 registers); 2 = one workgroup of 512 pixels per CU, a wave
+// owns 64 pixels (256 registers): every weight fragment read from LDS feeds two MFMAs instead of one, 0.75 KB of LDS reads per MFMA
+// instead of 1.25 -- with one tile per wave the main loop sits on the LDS port (16 waves x 20 KB per stage = 320 KB at 128 B/clk =
+// 2.5 k cycles + bank conflicts against 2.0 k of MFMA; measured 3.0 k, profiles/r03/d_...).
+template <int NW, int PT = 1> struct MidCfg {
+  static constexpr int PX = 32 * NW * PT;               // output pixels per workgroup
   // input-pixel slab bound, rows: a 12-wide phase packs PX pixels into PX/12+1 output rows (one input row each),
   // plus the row above the first one and one row of slack for the partial first/last rows
   static constexpr int PATCH = (PX / 12 + 3) * 12 + 16;
   static constexpr int OFF_W = (PATCH + 1) * M_PITCH * 2;       // bytes; row PATCH is all zero
-  static constexpr int MAIN_END = OFF_W + 2 * 16384;            // two weight tiles of [128 rows][64 k] at 128 B per row (XOR-swizzled)
-  static constexpr int T1_END = 32768 + NW * 32 * 144;          // ConvT#1 stage: half of its operands (4 tiles x 8 KB) + per-wave store tiles
+  static constexpr int NBUF = PT == 2 ? 3 : 2;                  // weight tiles in flight + the one being read: with one workgroup per CU nobody else covers a tile's load latency, so it is fetched two stages ahead
+  static constexpr int MAIN_END = OFF_W + NBUF * 16384;         // weight tiles of [128 rows][64 k] at 128 B per row (XOR-swizzled)
+  static constexpr int W1_LOADS = PT == 2 ? 1 : 2;              // ConvT#1's 64 KB of operands: in two halves, or (the larger workgroup has the LDS) at once
+  static constexpr int W1_BYTES = 65536 / W1_LOADS;
+  static constexpr int T1_END = W1_BYTES + NW * 32 * 144;       // ConvT#1 stage: its operands (8 KB tiles) + per-wave store tiles
   static constexpr int OFF_META = MAIN_END > T1_END ? MAIN_END : T1_END;
   static constexpr int LDS = OFF_META + 3 * PX * 4;
+  static_assert(PX <= 64 * NW * PT && (PT == 1 || PT == 2), "row tables are filled by one or two passes of the workgroup");
   static constexpr int NTHR = 64 * NW;
   static constexpr int WCH = 1024 / NTHR;               // weight-tile 16-byte chunks per thread
   static constexpr int PCH = (PATCH * 8 + NTHR - 1) / NTHR;  // patch chunks per thread
 };
 
-template <bool F16, int NW>
-__global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
-  using C = MidCfg<NW>;
-  static_assert(C::OFF_META >= 32768 + NW * 32 * 144, "ConvT#1 operand tiles (4 x 8 KB) + per-wave store tiles are staged over the patch + weight tiles");
+template <bool F16, int NW, int PT>
+__global__ void __launch_bounds__(64 * NW, PT == 2 ? 2 : (NW == 8 ? 4 : 1)) mid16(MidParams p) {
+  using C = MidCfg<NW, PT>;
+  static_assert(C::OFF_META >= C::T1_END, "ConvT#1 operand tiles + per-wave store tiles are staged over the patch + weight tiles");
   extern __shared__ __attribute__((aligned(16))) char msm[];
   uint16_t* Ps = reinterpret_cast<uint16_t*>(msm);
   uint16_t* Ws = reinterpret_cast<uint16_t*>(msm + C::OFF_W);
@@ -57,27 +65,28 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
   int* row_my = row_img + C::PX;
   int* row_mx = row_my + C::PX;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, l31 = lane & 31;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, l31 = lane & 31;
   const int phase = blockIdx.y, blk = blockIdx.x;
 #ifdef SRCFD_DIAG
-  unsigned long long tstamp[6];
+  unsigned long long tstamp[6], t_sync = 0, t_issue = 0, t_mma = 0, t_a = 0, t_b = 0;
   tstamp[0] = __builtin_amdgcn_s_memtime();
+#define MID_T(v) do { if (p.prof) { __builtin_amdgcn_sched_barrier(0); v = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #define MID_STAMP(i) do { if (p.prof) { __builtin_amdgcn_sched_barrier(0); tstamp[i] = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_sched_barrier(0); } } while (0)
 #else
 #define MID_STAMP(i) do { } while (0)
+#define MID_T(v) do { } while (0)
 #endif
   const int py = phase >> 1, px = phase & 1;
   const int TY = py ? 1 : 2, TX = px ? 1 : 2, NT = TY * TX;
   const int MH = py ? 12 : 13, MW = px ? 12 : 13, per = MH * MW;
   const int M = p.n * per, m0 = blk * C::PX;
   if (m0 >= M) return;
-  const uint16_t* Wt = p.w0[phase];
-  const int Kp = p.kpad[phase];
+  const uint16_t* Wt = p.w0t[phase];   // stage tiles, 16 KB each, already in LDS order
 
-  if (tid < C::PX) {
-    int m = m0 + tid, img = -1, my = 0, mx = 0;
+  for (int i = tid; i < C::PX; i += C::NTHR) {
+    int m = m0 + i, img = -1, my = 0, mx = 0;
     if (m < M) { img = m / per; int r = m - img * per; my = r / MW; mx = r - my * MW; }
-    row_img[tid] = img; row_my[tid] = my; row_mx[tid] = mx;
+    row_img[i] = img; row_my[i] = my; row_mx[i] = mx;
   }
   if (tid < M_PITCH / 2) reinterpret_cast<uint32_t*>(Ps + C::PATCH * M_PITCH)[tid] = 0;
   __syncthreads();
@@ -89,17 +98,20 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
   const int hi = row_img[mlast] * 144 + min(row_my[mlast], 11) * 12 + 11;
   const int NP = min(hi - lo + 1, C::PATCH);  // <= PATCH by construction; the clamp only guards LDS
 
-  // this lane's pixel and the patch row each tap reads
-  const int prow = wave * 32 + l31;
-  const int img = row_img[prow], my = row_my[prow], mx = row_mx[prow];
-  int trow[4];
+  // this lane's pixel(s) and the patch row each tap reads
+  int img[PT], my[PT], mx[PT], trow[PT][4];
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int ty = t / TX, tx = t - ty * TX;  // only t < NT is used
-    const int iy = my - ty, ix = mx - tx;
-    int r = img * 144 + iy * 12 + ix - lo;
-    const bool ok = img >= 0 && t < NT && (unsigned)iy < 12u && (unsigned)ix < 12u && (unsigned)r < (unsigned)C::PATCH;
-    trow[t] = (ok ? r : C::PATCH) * M_PITCH + h * 8;
+  for (int pt = 0; pt < PT; ++pt) {
+    const int prow = (wave * PT + pt) * 32 + l31;
+    img[pt] = row_img[prow]; my[pt] = row_my[prow]; mx[pt] = row_mx[prow];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int ty = t / TX, tx = t - ty * TX;  // only t < NT is used
+      const int iy = my[pt] - ty, ix = mx[pt] - tx;
+      int r = img[pt] * 144 + iy * 12 + ix - lo;
+      const bool ok = img[pt] >= 0 && t < NT && (unsigned)iy < 12u && (unsigned)ix < 12u && (unsigned)r < (unsigned)C::PATCH;
+      trow[pt][t] = (ok ? r : C::PATCH) * M_PITCH + h * 8;
+    }
   }
 
   // staging roles: 16-byte column c8 of rows xrow + (NTHR/8)*j
@@ -109,9 +121,10 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
   // prefetch), which serialised the global loads
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
   u32x4 pr[C::PCH];
-  // Weight tiles go global -> LDS directly (global_load_lds: no registers, no ds_write pass), two buffers.  The LDS image
-  // is lane-linear (chunk index = row * 8 + slot = tid + NTHR * j), so the bank swizzle sits on the SOURCE address: slot
-  // `sl` of row r holds k-chunk sl ^ ((r >> 1) & 7), and the fragment reads below apply the same XOR.
+  // Weight tiles go global -> LDS directly (global_load_lds: no registers, no ds_write pass), two or three buffers.  The LDS image
+  // is lane-linear (chunk index = row * 8 + slot = tid + NTHR * j) and the host stores every stage's tile in exactly that order
+  // (fused_bf16.hip: 16 KB of consecutive memory per stage), bank swizzle included: slot `sl` of row r holds k-chunk
+  // sl ^ ((r >> 1) & 7), and the fragment reads below apply the same XOR.
   // The builtin form of the instruction is known to hipcc as a pending LDS write: it then puts `s_waitcnt vmcnt(0)` in front of
   // the next ds_read -- here the fragment reads of the tile being COMPUTED -- which drains the prefetch before the MFMAs start
   // (seen in the ISA; the kernel gained nothing from the prefetch).  As an asm statement the load is outside hipcc's
@@ -120,37 +133,34 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
   // Addresses of the staging loads are a wave-uniform base (SGPR pair) + a 32-bit per-lane offset: as 64-bit per-lane pointers (round 2)
   // the five patch pointers alone took ten registers, hipcc spilled them, and every reload in the loop came with an
   // s_waitcnt vmcnt(0) that drained the weight tile in flight (seen in the ISA, round 3)
-  unsigned woff[C::WCH];
-#pragma unroll
-  for (int j = 0; j < C::WCH; ++j) {
-    const int r = xrow + RSTEP * j;
-    woff[j] = (unsigned)((r * Kp + ((c8 ^ ((r >> 1) & 7)) * 8)) * 2);
-  }
-  auto g2l_w = [&](int t, int c, int buf) {
-    const uint16_t* base = Wt + t * 256 + c * 64;     // wave-uniform
+  auto g2l_w = [&](int st, int buf) {   // stage st = chunk * taps + tap
 #pragma unroll
     for (int j = 0; j < C::WCH; ++j) {
+      const uint16_t* base = Wt + (size_t)st * 8192 + C::NTHR * j * 8;     // wave-uniform
       const unsigned dst = __builtin_amdgcn_readfirstlane(lds_w0 + (unsigned)(buf * 16384 + (wave * 64 + C::NTHR * j) * 16));
       unsigned keep;
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-                   : "=&s"(keep) : "v"(woff[j]), "s"(dst), "s"(base) : "memory");
+                   : "=&s"(keep) : "v"((unsigned)(tid * 16)), "s"(dst), "s"(base) : "memory");
     }
   };
-  const unsigned poff0 = (unsigned)(xrow * 512 + c8 * 16);   // byte offset of this thread's first patch chunk inside the slab
   auto g2r_p = [&](int c) {
     const char* base = reinterpret_cast<const char*>(p.in + (size_t)lo * 256 + c * 64);   // wave-uniform
 #pragma unroll
     for (int j = 0; j < C::PCH; ++j) {
-      const int r = xrow + RSTEP * j;
-      pr[j] = r < NP ? *reinterpret_cast<const u32x4*>(base + (poff0 + (unsigned)(RSTEP * j * 512))) : u32x4{0, 0, 0, 0};
+      // rows >= NP of the patch are never gathered (trow points past-the-slab pixels at the zero row), so they may hold anything: the
+      // load is unconditional from a clamped row -- a zero fill of the staging registers made hipcc wait for every load in flight
+      // (vmcnt(0), the weight tiles included) in front of the v_mov
+      const int r = min(xrow + RSTEP * j, NP - 1);
+      pr[j] = *reinterpret_cast<const u32x4*>(base + (unsigned)(r * 512 + c8 * 16));
     }
   };
   // ConvT#1's 64 KB of A operands (8 tiles of 8 KB = 512 chunks of 16 B, one per (tap, 32-channel half)) go through the LDS
   // the main loop has left, in two halves of four tiles, by global_load_lds (no registers: the accumulators, the packed
   // B operands and the swish temporaries fill the file in that stage); the waves work through a half without
   // synchronising with each other
-  constexpr int W1CH = 2048 / C::NTHR;
-  static_assert(W1CH * C::NTHR == 2048, "a half of ConvT#1's operands divides evenly over the workgroup");
+  constexpr int W1CHUNKS = C::W1_BYTES / 16;
+  constexpr int W1CH = W1CHUNKS / C::NTHR;
+  static_assert(W1CH * C::NTHR == W1CHUNKS, "a load of ConvT#1's operands divides evenly over the workgroup");
   const u32x4* w1g = reinterpret_cast<const u32x4*>(p.w1f);
   auto g2l_w1 = [&](int half) {   // lane-linear LDS image: wave w's j-th instruction fills chunks (w*64 + NTHR*j) .. +63
     // (asm, like the weight tiles above: with the builtin pending, hipcc put vmcnt(0) in front of every tile's first LDS read in
@@ -158,7 +168,7 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)msm;
 #pragma unroll
     for (int j = 0; j < W1CH; ++j) {
-      const u32x4* base = w1g + half * 2048 + C::NTHR * j;   // wave-uniform
+      const u32x4* base = w1g + half * W1CHUNKS + C::NTHR * j;   // wave-uniform
       const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)((wave * 64 + C::NTHR * j) * 16));
       unsigned keep;
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
@@ -174,42 +184,103 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
   };
 
   // accumulators start at the bias (ConvT#0 bias as an MFMA C operand)
-  f32x16 acc[4];
+  f32x16 acc[PT][4];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) acc[mt] = load_bias16(reinterpret_cast<const char*>(p.b0f) + (mt * 2 + h) * 64);
+  for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[pt][mt] = load_bias16(reinterpret_cast<const char*>(p.b0f) + (mt * 2 + h) * 64);
 
   const int NS = 4 * NT;  // stages: 64-channel chunk c = s / NT (outer), tap t = s % NT (inner)
-  if (!MID_ABL(4)) { g2r_p(0); g2l_w(0, 0, 0); }
+  constexpr int LA = C::NBUF - 1;   // stages a weight tile is fetched ahead of its use
+  if (!MID_ABL(4)) {
+    g2r_p(0);
+    g2l_w(0, 0);
+    if (LA == 2 && NS > 1) g2l_w(1, 1);
+  }
+  int bcur = 0;                     // ring slot of stage s
   // A-fragment reads: row mt*32 + l31, k-chunk 2 kk + h at slot (2 kk + h) ^ ((l31 >> 1) & 7) = (2 kk) ^ wbase
   const int wbase = h ^ ((l31 >> 1) & 7);
   const uint16_t* wsl = Ws + l31 * 64;
   for (int s = 0; s < NS; ++s) {
     const int c = s / NT, t = s - c * NT;
+#ifdef SRCFD_DIAG
+    MID_T(t_a);
+#endif
     if (t == 0) {
       if (s > 0) __syncthreads();   // every wave is past the previous chunk's last MFMAs before its patch is overwritten
       r2l_p();
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // tile s (asm global_load_lds, issued a stage ago) has landed in this wave's share
+    // tile s (asm global_load_lds, issued LA stages ago) has landed in this wave's share: with LA == 2 tile s + 1 (the WCH youngest
+    // loads) may still be in flight, except behind a patch load (t == 0: hipcc's own wait for the patch registers in r2l_p covered everything)
+    if (LA == 2 && s + 1 < NS && t != 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(C::WCH) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // ... and in everybody's; the patch is visible
     if (s == 0) MID_STAMP(2);
-    if (s + 1 < NS && !MID_ABL(4)) {
+#ifdef SRCFD_DIAG
+    MID_T(t_b); if (s > 0) t_sync += t_b - t_a;
+#endif
+    if (!MID_ABL(4)) {
       const int c1 = (s + 1) / NT, t1 = (s + 1) - c1 * NT;
-      if (t1 == 0) g2r_p(c1);
-      g2l_w(t1, c1, (s + 1) & 1);   // into the buffer stage s - 1 read: all waves finished it before the barrier above
+      if (s + 1 < NS && t1 == 0) g2r_p(c1);   // in front of the tile: hipcc's wait for the patch registers (next stage) is vmcnt(0) as far as it knows
+      if (s + LA < NS) {
+        int bn = bcur + LA; bn = bn >= C::NBUF ? bn - C::NBUF : bn;
+        g2l_w(s + LA, bn);   // into the buffer stage s - 1 read: all waves finished it before the barrier above
+      }
     }
-    const uint16_t* bsrc = Ps + trow[t];
-    const uint16_t* wsb = wsl + (s & 1) * 8192;
-    if (!MID_ABL(1))
+#ifdef SRCFD_DIAG
+    MID_T(t_a); t_issue += t_a - t_b;
+#endif
+    const uint16_t* bsrc[PT];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const uint4 bf = *reinterpret_cast<const uint4*>(bsrc + kk * 16);
-      const int wo = ((2 * kk) ^ wbase) * 8;
-      uint4 af[4];
+    for (int pt = 0; pt < PT; ++pt) bsrc[pt] = Ps + trow[pt][t];
+    const uint16_t* wsb = wsl + bcur * 8192;
+    bcur = bcur + 1 == C::NBUF ? 0 : bcur + 1;
+    if (!MID_ABL(1)) {
+      if constexpr (PT == 2) {
+        // Two waves per SIMD: nobody else fills the LDS round trip in front of a k-step's MFMAs, and left to itself hipcc re-reads every
+        // weight fragment into the same three register quads (two MFMAs, then a full LDS latency: the matrix pipe idled two thirds of a
+        // stage).  So the stage is software-pipelined by hand in units of one weight fragment (two MFMAs, 64 cycles): the fragment of
+        // unit u + 3 is read into a ring of four quads while unit u runs, the two pixel fragments of k-step kk + 1 at the start of kk.
+        // (Double-buffering all six fragments of a k-step -- 48 registers -- spilled, and a reload in the ConvT#1 stage waits on vmcnt
+        // behind that stage's global stores.)
+        uint4 bf[2][PT], af[4];
+        auto rd_a = [&](const int u) {   // unit u = (k-step u >> 2, channel tile u & 3)
+          af[u & 3] = *reinterpret_cast<const uint4*>(wsb + (u & 3) * 32 * 64 + ((2 * (u >> 2)) ^ wbase) * 8);
+        };
+        auto rd_b = [&](const int kk) {
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) af[mt] = *reinterpret_cast<const uint4*>(wsb + mt * 32 * 64 + wo);
+          for (int pt = 0; pt < PT; ++pt) bf[kk & 1][pt] = *reinterpret_cast<const uint4*>(bsrc[pt] + kk * 16);
+        };
+        rd_b(0); rd_a(0); rd_a(1); rd_a(2);
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma32<F16>(af[mt], bf, acc[mt]);
+        for (int u = 0; u < 16; ++u) {
+          if (u + 3 < 16) rd_a(u + 3);
+          if ((u & 3) == 0 && u < 12) rd_b((u >> 2) + 1);
+          pin();
+#pragma unroll
+          for (int pt = 0; pt < PT; ++pt) acc[pt][u & 3] = mfma32<F16>(af[u & 3], bf[(u >> 2) & 1][pt], acc[pt][u & 3]);
+          pin();
+        }
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          uint4 bf[PT];
+#pragma unroll
+          for (int pt = 0; pt < PT; ++pt) bf[pt] = *reinterpret_cast<const uint4*>(bsrc[pt] + kk * 16);
+          const int wo = ((2 * kk) ^ wbase) * 8;
+          uint4 af[4];
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt) af[mt] = *reinterpret_cast<const uint4*>(wsb + mt * 32 * 64 + wo);
+#pragma unroll
+          for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) acc[pt][mt] = mfma32<F16>(af[mt], bf[pt], acc[pt][mt]);
+        }
+      }
     }
+#ifdef SRCFD_DIAG
+    MID_T(t_b); t_mma += t_b - t_a;
+#endif
   }
   __syncthreads();   // the ConvT#1 stage re-uses the patch and weight space
   MID_STAMP(3);
@@ -217,9 +288,11 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
   // ---- ConvT#0 epilogue: swish, pack; the packed accumulators are ConvT#1's B operands ----
   // ConvT#1's first operand half is in flight during the swish below
   if (!MID_ABL(2)) g2l_w1(0);
-  uint32_t fb[4][8];
+  uint32_t fb[PT][4][8];
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) swish_pack16<F16>(acc[mt], fb[mt]);
+  for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) swish_pack16<F16>(acc[pt][mt], fb[pt][mt]);
 
   MID_STAMP(4);
   // ---- ConvT#1: 8 tiles of 32 rows (tap = j8 >> 1, channels 32*(j8&1)..+31), K = 128 = 8 k-steps.
@@ -227,31 +300,41 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
   // Each tap's 32 pixels x 64 channels are transposed through a wave-private LDS tile so that the
   // global stores are whole 128-byte pixel rows (16 B per lane, 8 lanes per pixel) instead of
   // 8-byte pieces 512 B apart -- the scattered form was store-issue bound (~0.06 ms per batch).
-  uint4* w1s = reinterpret_cast<uint4*>(msm);          // four 8 KB operand tiles
-  char* stage = msm + 32768 + wave * (32 * 144);       // [32 pixels][144 B]
-  const int Y = 2 * my + py, X = 2 * mx + px;  // 25x25-level pixel
-  const int obase = img >= 0 ? ((img * 50 + 2 * Y) * 50 + 2 * X) * 64 : -1;  // element offset of tap (0,0)
+  uint4* w1s = reinterpret_cast<uint4*>(msm);          // 8 KB operand tiles (four or all eight resident)
+  char* stage = msm + C::W1_BYTES + wave * (32 * 144);  // [32 pixels][144 B]
+  int obase[PT];                                        // element offset of tap (0,0) of the lane's pixel(s)
+#pragma unroll
+  for (int pt = 0; pt < PT; ++pt) {
+    const int Y = 2 * my[pt] + py, X = 2 * mx[pt] + px;  // 25x25-level pixel
+    obase[pt] = img[pt] >= 0 ? ((img[pt] * 50 + 2 * Y) * 50 + 2 * X) * 64 : -1;
+  }
   if (!MID_ABL(2)) {
     // ConvT#1's bias fragments go to LDS (the row tables there are dead): read from memory at the top of every tile they made
     // the tile's first MFMA wait on vmcnt -- an in-order counter that also holds the previous tap's global stores
     if (tid < 64) reinterpret_cast<float*>(msm + C::OFF_META)[tid] = p.b1f[tid];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the first operand half has landed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the first operand load has landed
     __syncthreads();
-    // Round 3: software-pipelined by one tile.  The eight MFMAs of tile jj + 1 are issued INSIDE the swish block of tile jj, one after
-    // every four transcendentals of this wave's own stream (dev16.h swish_pack_s; tools/microbench9.hip: an MFMA there costs the SIMD
-    // about its 8 issue cycles instead of its 32), each with its A fragment read from LDS one hook earlier.  Tiles 0 and 4 (the first
-    // of either operand half) are issued in front of the loop / behind the reload.  Same instructions per element: bit-identical.
+    // Round 3: software-pipelined by one tile.  The eight MFMAs of the next tile are issued INSIDE the swish block of the current one, one
+    // after every four transcendentals of this wave's own stream (dev16.h swish_pack_s; tools/microbench9.hip: an MFMA there costs the SIMD
+    // about its 8 issue cycles instead of its 32), each with its A fragment read from LDS one hook earlier.  The first tile of an operand
+    // load is issued in front of the loop / behind the reload.  Same instructions per element: bit-identical.
+    // Item i of the stage = (operand load i / (TPL * PT), pixel tile pt, operand tile jj): with two pixel tiles per wave both run
+    // through the resident operand tiles before the next load.
     f32x2 one2 = {1.0f, 1.0f};
     asm volatile("" : "+v"(one2));
     f32x16 a1[2];
-    auto bfrag = [&](const int s) { return make_uint4(fb[s >> 1][4 * (s & 1)], fb[s >> 1][4 * (s & 1) + 1], fb[s >> 1][4 * (s & 1) + 2], fb[s >> 1][4 * (s & 1) + 3]); };
-    auto issue_tile = [&](const int jj, f32x16& a) {       // all eight MFMAs back to back (nothing to hide them under)
+    constexpr int TPL = 8 / C::W1_LOADS;     // operand tiles per load
+    constexpr int NI = 8 * PT;               // items
+    auto item_pt = [](const int i) { return (i % (TPL * PT)) / TPL; };
+    auto item_jj = [](const int i) { return (i / (TPL * PT)) * TPL + i % TPL; };
+    auto bfrag = [&](const int pt, const int s) { return make_uint4(fb[pt][s >> 1][4 * (s & 1)], fb[pt][s >> 1][4 * (s & 1) + 1], fb[pt][s >> 1][4 * (s & 1) + 2], fb[pt][s >> 1][4 * (s & 1) + 3]); };
+    auto issue_tile = [&](const int pt, const int jj, f32x16& a) {       // all eight MFMAs back to back (nothing to hide them under)
       a = load_bias16(msm + C::OFF_META + ((jj & 1) * 2 + h) * 64);
-      const uint4* wt = w1s + (jj & 3) * 512 + lane;
+      const uint4* wt = w1s + (jj % TPL) * 512 + lane;
 #pragma unroll
-      for (int s = 0; s < 8; ++s) a = mfma32<F16>(wt[s * 64], bfrag(s), a);
+      for (int s = 0; s < 8; ++s) a = mfma32<F16>(wt[s * 64], bfrag(pt, s), a);
     };
-    auto tile_out = [&](const int jj, const uint32_t (&o)[8]) {
+    auto tile_out = [&](const int pt, const int jj, const uint32_t (&o)[8]) {
       const int tap = jj >> 1, jh = jj & 1;
 #pragma unroll
       for (int q = 0; q < 4; ++q)
@@ -262,42 +345,47 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int pix = (lane >> 3) + 8 * r;
-          const int ob = __shfl(obase, pix, 64);
+          const int ob = __shfl(obase[pt], pix, 64);
           const uint4 v = *reinterpret_cast<const uint4*>(stage + pix * 144 + (lane & 7) * 16);
           if (ob >= 0 && !MID_ABL(8)) *reinterpret_cast<uint4*>(p.out + ob + toff + (lane & 7) * 8) = v;
         }
       }
     };
-    issue_tile(0, a1[0]);
+    issue_tile(0, 0, a1[0]);
 #pragma unroll
-    for (int jj = 0; jj < 8; ++jj) {
+    for (int i = 0; i < NI; ++i) {
       uint32_t o[8];
-      constexpr int dummy = 0; (void)dummy;
-      if (jj + 1 < 8 && jj + 1 != 4 && !MID_ABL(16)) {
-        f32x16& an = a1[(jj + 1) & 1];
-        an = load_bias16(msm + C::OFF_META + (((jj + 1) & 1) * 2 + h) * 64);
-        const uint4* wt = w1s + ((jj + 1) & 3) * 512 + lane;
+      const int pt = item_pt(i), jj = item_jj(i);
+      const bool reload_next = C::W1_LOADS == 2 && i + 1 == NI / 2;   // the next item is the first of the second operand half
+      if (i + 1 < NI && !reload_next && !MID_ABL(16)) {
+        const int ptn = item_pt(i + 1), jjn = item_jj(i + 1);
+        f32x16& an = a1[(i + 1) & 1];
+        an = load_bias16(msm + C::OFF_META + ((jjn & 1) * 2 + h) * 64);
+        const uint4* wt = w1s + (jjn % TPL) * 512 + lane;
         uint4 wf = wt[0];
-        swish_pack_s<F16, 0, 16>(a1[jj & 1], o, one2, [&](auto k) {
+        swish_pack_s<F16, 0, 16>(a1[i & 1], o, one2, [&](auto k) {
           constexpr int S = decltype(k)::value;
-          an = mfma32<F16>(wf, bfrag(S), an);
+          an = mfma32<F16>(wf, bfrag(ptn, S), an);
           if constexpr (S < 7) wf = wt[(S + 1) * 64];      // the next fragment, into the register the MFMA has just read
         });
       } else {
-        swish_pack16<F16>(a1[jj & 1], o, MID_ABL(16));
-        if (jj + 1 < 8 && jj + 1 != 4) issue_tile(jj + 1, a1[(jj + 1) & 1]);   // (diagnostic no-swish build)
+        swish_pack16<F16>(a1[i & 1], o, MID_ABL(16));
+        if (i + 1 < NI && !reload_next) issue_tile(item_pt(i + 1), item_jj(i + 1), a1[(i + 1) & 1]);   // (diagnostic no-swish build)
       }
-      tile_out(jj, o);
-      if (jj == 3) {   // second half of the operands: the only point of the stage where the waves meet (its load latency is exposed once)
+      tile_out(pt, jj, o);
+      if (reload_next) {   // second half of the operands: the only point of the stage where the waves meet (its load latency is exposed once)
         __syncthreads();
         g2l_w1(1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        issue_tile(4, a1[0]);
+        issue_tile(item_pt(i + 1), item_jj(i + 1), a1[(i + 1) & 1]);
       }
     }
   }
 #ifdef SRCFD_DIAG
+  if (p.prof && blk == 3 && phase == 0 && lane == 0 && wave < 8) {   // one workgroup of the longest phase, every wave
+    p.prof[36 + wave * 3 + 0] = t_sync; p.prof[36 + wave * 3 + 1] = t_issue; p.prof[36 + wave * 3 + 2] = t_mma;
+  }
   if (p.prof && tid == 0) {
     const unsigned long long t5 = __builtin_amdgcn_s_memtime();
     atomicAdd(p.prof + phase * 6 + 0, 1ull);
@@ -306,14 +394,17 @@ __global__ void __launch_bounds__(64 * NW, NW == 8 ? 4 : 1) mid16(MidParams p) {
     atomicAdd(p.prof + phase * 6 + 3, tstamp[3] - tstamp[2]);
     atomicAdd(p.prof + phase * 6 + 4, tstamp[4] - tstamp[3]);
     atomicAdd(p.prof + phase * 6 + 5, t5 - tstamp[4]);
+    atomicAdd(p.prof + 24 + phase * 3 + 0, t_sync);
+    atomicAdd(p.prof + 24 + phase * 3 + 1, t_issue);
+    atomicAdd(p.prof + 24 + phase * 3 + 2, t_mma);
   }
 #endif
 }
 
-template <bool F16, int NW>
+template <bool F16, int NW, int PT = 1>
 static hipError_t launch_mid16_nw(const MidParams& p, hipStream_t s) {
-  using C = MidCfg<NW>;
-  void (*fn)(MidParams) = mid16<F16, NW>;
+  using C = MidCfg<NW, PT>;
+  void (*fn)(MidParams) = mid16<F16, NW, PT>;
   hipError_t e = lds_attr_once(reinterpret_cast<const void*>(fn), C::LDS);
   if (e != hipSuccess) return e;
   const int blocks = (p.n * 169 + C::PX - 1) / C::PX;  // the largest phase (13x13 pixels per sample)
@@ -325,6 +416,7 @@ hipError_t launch_mid16(bool f16, const MidParams& p, int waves, hipStream_t s) 
   if (p.n == 0) return hipSuccess;
   if (waves == 4) return f16 ? launch_mid16_nw<true, 4>(p, s) : launch_mid16_nw<false, 4>(p, s);
   if (waves == 16) return f16 ? launch_mid16_nw<true, 16>(p, s) : launch_mid16_nw<false, 16>(p, s);
+  if (waves == 82) return f16 ? launch_mid16_nw<true, 8, 2>(p, s) : launch_mid16_nw<false, 8, 2>(p, s);   // 8 waves x 2 pixel tiles: 512 pixels per workgroup, one per CU
   return f16 ? launch_mid16_nw<true, 8>(p, s) : launch_mid16_nw<false, 8>(p, s);
 }
 
