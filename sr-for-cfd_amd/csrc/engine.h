@@ -37,17 +37,19 @@ struct FusedState;  // bf16/f16 path (fused_bf16.hip)
 struct Switches {
   bool enc16 = true;     // SRCFD_ENC=0: layer-by-layer 16-bit encoder instead of the one-launch enc16
   bool mid16 = true;     // SRCFD_MID=0: generic GEMMs instead of the fused ConvT#0 -> ConvT#1 kernel
-  bool mid_wide = true;  // mid16 with 512-pixel workgroups, one per CU, two pixel tiles per wave (SRCFD_MID=2, the default); SRCFD_MID=1: 256-pixel workgroups, two per CU
+  int mid_shape = 3;     // workgroup shape of mid16 (SRCFD_MID=1, 2, 3): 1 = 8 waves x 32 pixels, two workgroups per CU (128 registers; rounds 1-2);
+                         // 2 = 8 waves x 64 pixels, one per CU; 3 = 4 waves x 64 pixels, two per CU (256 registers; default)
   bool dense1_16 = true; // SRCFD_DENSE1=0: dense_1 on the generic 16-bit GEMM
   bool enc32 = true;     // SRCFD_NO_ENC32=1: layer-by-layer f32 encoder
   bool skinny32 = true;  // SRCFD_NO_DENSE_SKINNY=1: dense_1 on the generic f32 GEMM
   bool tail16s = false;  // SRCFD_TAIL=s: the software-pipelined 8-wave tail kernel (kernels_tail16.hip) instead of the 16-wave, stage-by-stage one (measured slower)
+  int mid_waves = 0;     // SRCFD_MID_WAVES: other workgroup shapes of mid16 (4, 16: waves per workgroup at 32 pixels per wave); 0 = the shape mid_shape selects
   int tail_seg = 0;      // SRCFD_TAIL_SEG: segments per sample of the 16-bit tail (1, 2, 5, 10, 25); 0 = chosen per batch
   unsigned bits() const {
     return (enc16 ? 1u : 0u) | (mid16 ? 2u : 0u) | (dense1_16 ? 4u : 0u) | (enc32 ? 8u : 0u) | (skinny32 ? 16u : 0u) | (tail16s ? 32u : 0u) |
-           (mid_wide ? 64u : 0u) | ((unsigned)tail_seg << 8);
+           ((unsigned)mid_shape << 6) | ((unsigned)tail_seg << 8) | ((unsigned)mid_waves << 16);
   }
-  bool all_default() const { return enc16 && mid16 && mid_wide == Switches().mid_wide && dense1_16 && enc32 && skinny32 && !tail16s && tail_seg == 0; }
+  bool all_default() const { return enc16 && mid16 && mid_shape == Switches().mid_shape && dense1_16 && enc32 && skinny32 && !tail16s && tail_seg == 0 && mid_waves == 0; }
   static Switches from_env();
 };
 

@@ -300,11 +300,12 @@ Switches Switches::from_env() {
   Switches w;
   w.enc16 = on("SRCFD_ENC", true);
   w.mid16 = on("SRCFD_MID", true);
-  { const char* e = getenv("SRCFD_MID"); if (e && atoi(e) != 0) w.mid_wide = atoi(e) == 2; }
+  { const char* e = getenv("SRCFD_MID"); const int v = e ? atoi(e) : 0; if (v >= 1 && v <= 3) w.mid_shape = v; }
   w.dense1_16 = on("SRCFD_DENSE1", true);
   w.enc32 = !on("SRCFD_NO_ENC32", false);
   w.skinny32 = !on("SRCFD_NO_DENSE_SKINNY", false);
   { const char* t = getenv("SRCFD_TAIL"); w.tail16s = t && t[0] == 's'; }
+  { const char* e = getenv("SRCFD_MID_WAVES"); const int v = e ? atoi(e) : 0; w.mid_waves = (v == 4 || v == 16) ? v : 0; }
   const char* e = getenv("SRCFD_TAIL_SEG");
   const int seg = e ? atoi(e) : 0;
   w.tail_seg = (seg == 1 || seg == 2 || seg == 5 || seg == 10 || seg == 25) ? seg : 0;
@@ -952,7 +953,7 @@ int srcfd_model_last_plan(const srcfd_model* m, char* buf, size_t buf_len) {
   char tmp[256];
   if (p.fused)
     snprintf(tmp, sizeof(tmp), "precision=%s encoder=%s dense_1=%s middle=%s tail=%s tail_seg=%d graph=%s", prec, p.sw.enc16 ? "enc16" : "layers",
-             p.sw.dense1_16 ? "dense1_16" : "gemm16", p.sw.mid16 ? (p.sw.mid_wide ? "mid16w" : "mid16") : "gemm16", p.sw.tail16s ? "tail16s" : "tail16", p.tail_seg,
+             p.sw.dense1_16 ? "dense1_16" : "gemm16", p.sw.mid16 ? (p.sw.mid_waves == 4 ? "mid16_4x32" : p.sw.mid_waves == 16 ? "mid16_16x32" : p.sw.mid_shape == 1 ? "mid16_8x32" : p.sw.mid_shape == 2 ? "mid16_8x64" : "mid16_4x64") : "gemm16", p.sw.tail16s ? "tail16s" : "tail16", p.tail_seg,
              p.graph == 2 ? "replay" : p.graph == 1 ? "capture" : "eager");
   else
     snprintf(tmp, sizeof(tmp), "precision=%s encoder=%s dense_1=%s graph=%s", prec, p.sw.enc32 ? "enc32" : "layers",

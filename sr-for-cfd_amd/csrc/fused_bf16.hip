@@ -471,12 +471,8 @@ int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, cons
       if (mprof && !d_mprof) { HIPCHECK(hipMalloc(&d_mprof, 60 * sizeof(unsigned long long))); }
       if (mprof) { HIPCHECK(hipMemsetAsync(d_mprof, 0, 60 * sizeof(unsigned long long), s)); mp.prof = d_mprof; }
 #endif
-      static const int mid_waves = [] {  // read once; anything but 4 / 8 / 16 waves per workgroup is ignored
-        const char* e = getenv("SRCFD_MID_WAVES");
-        const int v = e ? atoi(e) : 8;
-        return (v == 4 || v == 8 || v == 16) ? v : 8;
-      }();
-      rc = m.launch("mid(convT0+convT1)", s, [&] { return launch_mid16(f16, mp, m.sw.mid_wide ? 82 : mid_waves, s); });
+      const int mid_waves = m.sw.mid_waves ? m.sw.mid_waves : (m.sw.mid_shape == 1 ? 8 : m.sw.mid_shape == 2 ? 82 : 42);
+      rc = m.launch("mid(convT0+convT1)", s, [&] { return launch_mid16(f16, mp, mid_waves, s); });
       if (rc) return rc;
 #ifdef SRCFD_DIAG
       if (mprof && ++mprof_calls == 20) {

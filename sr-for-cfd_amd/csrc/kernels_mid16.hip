@@ -41,9 +41,9 @@ template <int NW, int PT = 1> struct MidCfg {
   // plus the row above the first one and one row of slack for the partial first/last rows
   static constexpr int PATCH = (PX / 12 + 3) * 12 + 16;
   static constexpr int OFF_W = (PATCH + 1) * M_PITCH * 2;       // bytes; row PATCH is all zero
-  static constexpr int NBUF = PT == 2 ? 3 : 2;                  // weight tiles in flight + the one being read: with one workgroup per CU nobody else covers a tile's load latency, so it is fetched two stages ahead
+  static constexpr int NBUF = (PT == 2 && NW == 8) ? 3 : 2;                  // weight tiles in flight + the one being read: with one workgroup per CU nobody else covers a tile's load latency, so it is fetched two stages ahead
   static constexpr int MAIN_END = OFF_W + NBUF * 16384;         // weight tiles of [128 rows][64 k] at 128 B per row (XOR-swizzled)
-  static constexpr int W1_LOADS = PT == 2 ? 1 : 2;              // ConvT#1's 64 KB of operands: in two halves, or (the larger workgroup has the LDS) at once
+  static constexpr int W1_LOADS = (PT == 2 && NW == 8) ? 1 : 2;              // ConvT#1's 64 KB of operands: in two halves, or (the larger workgroup has the LDS) at once
   static constexpr int W1_BYTES = 65536 / W1_LOADS;
   static constexpr int T1_END = W1_BYTES + NW * 32 * 144;       // ConvT#1 stage: its operands (8 KB tiles) + per-wave store tiles
   static constexpr int OFF_META = MAIN_END > T1_END ? MAIN_END : T1_END;
@@ -219,14 +219,16 @@ __global__ void __launch_bounds__(64 * NW, PT == 2 ? 2 : (NW == 8 ? 4 : 1)) mid1
 #ifdef SRCFD_DIAG
     MID_T(t_b); if (s > 0) t_sync += t_b - t_a;
 #endif
-    if (!MID_ABL(4)) {
+    int bnext = bcur + LA; bnext = bnext >= C::NBUF ? bnext - C::NBUF : bnext;
+    auto issue_loads = [&]() {
+      if (MID_ABL(4)) return;
       const int c1 = (s + 1) / NT, t1 = (s + 1) - c1 * NT;
       if (s + 1 < NS && t1 == 0) g2r_p(c1);   // in front of the tile: hipcc's wait for the patch registers (next stage) is vmcnt(0) as far as it knows
-      if (s + LA < NS) {
-        int bn = bcur + LA; bn = bn >= C::NBUF ? bn - C::NBUF : bn;
-        g2l_w(s + LA, bn);   // into the buffer stage s - 1 read: all waves finished it before the barrier above
-      }
-    }
+      if (s + LA < NS) g2l_w(s + LA, bnext);   // into the buffer stage s - 1 read: all waves finished it before the barrier above
+    };
+    // One workgroup per CU: the loads of later stages are not what a wave leaving the barrier should spend its first cycles on -- its
+    // own fragment reads and MFMAs are; the loads go out a few units into the stage (they have two stages to land)
+    if (PT == 1) issue_loads();
 #ifdef SRCFD_DIAG
     MID_T(t_a); t_issue += t_a - t_b;
 #endif
@@ -256,6 +258,7 @@ __global__ void __launch_bounds__(64 * NW, PT == 2 ? 2 : (NW == 8 ? 4 : 1)) mid1
         for (int u = 0; u < 16; ++u) {
           if (u + 3 < 16) rd_a(u + 3);
           if ((u & 3) == 0 && u < 12) rd_b((u >> 2) + 1);
+          if (u == 2) issue_loads();
           pin();
 #pragma unroll
           for (int pt = 0; pt < PT; ++pt) acc[pt][u & 3] = mfma32<F16>(af[u & 3], bf[(u >> 2) & 1][pt], acc[pt][u & 3]);
@@ -416,6 +419,7 @@ hipError_t launch_mid16(bool f16, const MidParams& p, int waves, hipStream_t s) 
   if (p.n == 0) return hipSuccess;
   if (waves == 4) return f16 ? launch_mid16_nw<true, 4>(p, s) : launch_mid16_nw<false, 4>(p, s);
   if (waves == 16) return f16 ? launch_mid16_nw<true, 16>(p, s) : launch_mid16_nw<false, 16>(p, s);
+  if (waves == 42) return f16 ? launch_mid16_nw<true, 4, 2>(p, s) : launch_mid16_nw<false, 4, 2>(p, s);   // 4 waves x 2 pixel tiles: 256 pixels per workgroup, two per CU, one wave of either on a SIMD
   if (waves == 82) return f16 ? launch_mid16_nw<true, 8, 2>(p, s) : launch_mid16_nw<false, 8, 2>(p, s);   // 8 waves x 2 pixel tiles: 512 pixels per workgroup, one per CU
   return f16 ? launch_mid16_nw<true, 8>(p, s) : launch_mid16_nw<false, 8>(p, s);
 }

@@ -398,7 +398,7 @@ class SRModel:
 
     def last_plan(self) -> dict:
         """Test hook (srcfd_model_last_plan): which implementation of each stage the last forward ran, e.g.
-        {'precision': 'bf16', 'encoder': 'enc16', 'dense_1': 'dense1_16', 'middle': 'mid16w', 'tail': 'tail16', 'tail_seg': '10', 'graph': 'eager'}."""
+        {'precision': 'bf16', 'encoder': 'enc16', 'dense_1': 'dense1_16', 'middle': 'mid16_4x64', 'tail': 'tail16', 'tail_seg': '10', 'graph': 'eager'}."""
         buf = C.create_string_buffer(512)
         L.check(L.lib.srcfd_model_last_plan(self._h, buf, len(buf)))
         return dict(w.split("=", 1) for w in buf.value.decode().split())

@@ -158,11 +158,11 @@ def test_bench_refuses_mismatched_world_and_diagnostic_switches():
         rc, recs, err = _run_bench([], {var: "1"})
         assert rc != 0 and not recs and var in err
     # A/B switches select another implementation than the shipped one: no headline under them either
-    for var, val in (("SRCFD_ENC", "0"), ("SRCFD_MID", "0"), ("SRCFD_MID", "1"), ("SRCFD_DENSE1", "0"), ("SRCFD_NO_ENC32", "1"), ("SRCFD_NO_DENSE_SKINNY", "1"),
+    for var, val in (("SRCFD_ENC", "0"), ("SRCFD_MID", "0"), ("SRCFD_MID", "1"), ("SRCFD_MID", "2"), ("SRCFD_DENSE1", "0"), ("SRCFD_NO_ENC32", "1"), ("SRCFD_NO_DENSE_SKINNY", "1"),
                      ("SRCFD_TAIL", "s"), ("SRCFD_TAIL_SEG", "5"), ("SRCFD_LIB", "/nonexistent/libsrcfd.so")):
         rc, recs, err = _run_bench([], {var: val})
         assert rc != 0 and not recs and var in err, (var, err[-300:])
-    rc, recs, err = _run_bench(["--gpus", "2"], {"SRCFD_BENCH_DRYRUN": "1", "SRCFD_ENC": "1", "SRCFD_MID": "2"})   # the default value of a switch is no switch
+    rc, recs, err = _run_bench(["--gpus", "2"], {"SRCFD_BENCH_DRYRUN": "1", "SRCFD_ENC": "1", "SRCFD_MID": "3"})   # the default value of a switch is no switch
     assert rc == 0 and len(recs) == 1
 
 

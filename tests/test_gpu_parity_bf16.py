@@ -59,12 +59,12 @@ def refs(srcfd, oracle, enc_weights, dec_weights, coarse_cases):
     return out
 
 
-@pytest.mark.parametrize("mid", ["2", "1", "0"], ids=["fused_mid_512px", "fused_mid_256px", "generic_gemm"])
+@pytest.mark.parametrize("mid", ["3", "2", "1", "0"], ids=["fused_mid_4x64", "fused_mid_8x64", "fused_mid_8x32", "generic_gemm"])
 @pytest.mark.parametrize("kind", ["bf16", "f16"])
 def test_intermediate_activations(srcfd, oracle, enc_weights, dec_weights, refs, kind, mid, monkeypatch):
     """ConvT#1 output (50x50x64) before the fused tail, from both implementations of the middle
-    of the network: the fused ConvT#0->ConvT#1 kernel with 512-pixel workgroups (default, SRCFD_MID=2) or 256-pixel ones
-    (SRCFD_MID=1), and the generic 16-bit implicit GEMMs (SRCFD_MID=0), which also expose ConvT#0's output (25x25x128)."""
+    of the network: the fused ConvT#0->ConvT#1 kernel in its three workgroup shapes (SRCFD_MID=3, the default: 4 waves x 64 pixels;
+    2: 8 x 64; 1: 8 x 32) and the generic 16-bit implicit GEMMs (SRCFD_MID=0), which also expose ConvT#0's output (25x25x128)."""
     require_gpu(srcfd)
     from oracle import sr_oracle_lowp as lp
     monkeypatch.setenv("SRCFD_MID", mid)
@@ -72,7 +72,7 @@ def test_intermediate_activations(srcfd, oracle, enc_weights, dec_weights, refs,
     m.precision = kind
     x = refs["x"]
     y = m.predict(x)
-    assert m.last_plan()["middle"] == {"2": "mid16w", "1": "mid16", "0": "gemm16"}[mid]
+    assert m.last_plan()["middle"] == {"3": "mid16_4x64", "2": "mid16_8x64", "1": "mid16_8x32", "0": "gemm16"}[mid]
     _, acts = refs[kind]
     n = x.shape[0]
     conv = lp.bf16_bits_to_f32 if kind == "bf16" else (lambda b: b.view(np.float16).astype(np.float32))
@@ -101,12 +101,12 @@ def test_full_model(srcfd, oracle, enc_weights, dec_weights, refs, kind):
     per = per_sample_rel_l2(y, refs[kind][0])
     print(f"{kind}: per-sample rel L2 vs emulation {np.array2string(per, precision=2)}; median {np.median(per):.2e}")
     assert np.median(per) <= MEDIAN_EMU[kind]
-    assert m.last_plan()["encoder"] == "enc16" and m.last_plan()["middle"] == "mid16w"
+    assert m.last_plan()["encoder"] == "enc16" and m.last_plan()["middle"] == "mid16_4x64"
 
 
 @pytest.mark.parametrize("kind", ["bf16", "f16"])
-def test_the_two_workgroup_shapes_of_the_fused_middle_agree_bit_for_bit(srcfd, enc_weights, dec_weights, kind, monkeypatch):
-    """mid16 with 512-pixel workgroups (two pixel tiles per wave, three weight tiles in flight) and with 256-pixel ones run the same
+def test_the_workgroup_shapes_of_the_fused_middle_agree_bit_for_bit(srcfd, enc_weights, dec_weights, kind, monkeypatch):
+    """mid16 with 4 waves x 64 pixels (default), 8 x 64 (three weight tiles in flight) and 8 x 32 per workgroup run the same
     products in the same order per output: identical bits, for batches whose last workgroup of a phase is full, partial or alone."""
     require_gpu(srcfd)
     rng = np.random.default_rng(11)
@@ -115,15 +115,15 @@ def test_the_two_workgroup_shapes_of_the_fused_middle_agree_bit_for_bit(srcfd, e
     for n in (1, 3, 7, 50, 303):
         x = rng.standard_normal((n, 10, 10, 1)).astype(np.float32)
         outs = {}
-        for mid in ("1", "2"):
+        for mid in ("1", "2", "3"):
             monkeypatch.setenv("SRCFD_MID", mid)
             outs[mid] = m.predict(x).copy()
-            assert m.last_plan()["middle"] == ("mid16w" if mid == "2" else "mid16")
+            assert m.last_plan()["middle"] == {"1": "mid16_8x32", "2": "mid16_8x64", "3": "mid16_4x64"}[mid]
             if n <= 50:   # (the hook sees the workspace of the last chunk of a large batch only)
                 outs[mid + "a"] = m.debug_activation(0, (n, 50, 50, 64)).copy()
         if n <= 50:
-            assert np.array_equal(outs["1a"], outs["2a"]), f"n={n}: ConvT#1 activations differ"
-        assert np.array_equal(outs["1"], outs["2"]), f"n={n}"
+            assert np.array_equal(outs["1a"], outs["2a"]) and np.array_equal(outs["1a"], outs["3a"]), f"n={n}: ConvT#1 activations differ"
+        assert np.array_equal(outs["1"], outs["2"]) and np.array_equal(outs["1"], outs["3"]), f"n={n}"
 
 
 @pytest.mark.parametrize("kind", ["bf16", "f16"])
