@@ -55,7 +55,7 @@ REFUSED_ENV = ("SRCFD_TAIL_ABLATE", "SRCFD_MID_ABLATE", "SRCFD_TAIL_PROF")   # s
 AB_ENV_OFF_WHEN_ZERO = ("SRCFD_ENC", "SRCFD_DENSE1")
 AB_ENV_DEFAULT_VALUE = {"SRCFD_MID": "3"}    # workgroup shape of mid16: 3 = 4 waves x 64 pixels (shipped), 2 = 8 x 64, 1 = 8 x 32; 0 = generic GEMMs
 AB_ENV_ON_WHEN_SET = ("SRCFD_NO_ENC32", "SRCFD_NO_DENSE_SKINNY", "SRCFD_NO_TAIL32", "SRCFD_NO_GEMM32_BIG", "SRCFD_NO_PAIR", "SRCFD_NO_TRIPLE")
-AB_ENV_ANY_VALUE = ("SRCFD_TAIL", "SRCFD_TAIL_SEG", "SRCFD_MID_WAVES", "SRCFD_GRAPH", "SRCFD_LIB", "SRCFD_TRAIN_OVERLAP", "SRCFD_TRAIN_GRAPH",
+AB_ENV_ANY_VALUE = ("SRCFD_TAIL", "SRCFD_TAIL_SEG", "SRCFD_MID_WAVES", "SRCFD_MID_ORDER", "SRCFD_GRAPH", "SRCFD_LIB", "SRCFD_TRAIN_OVERLAP", "SRCFD_TRAIN_GRAPH",
                     "SRCFD_TRAIN_FUSE")
 
 

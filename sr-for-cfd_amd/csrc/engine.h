@@ -44,12 +44,13 @@ struct Switches {
   bool skinny32 = true;  // SRCFD_NO_DENSE_SKINNY=1: dense_1 on the generic f32 GEMM
   bool tail16s = false;  // SRCFD_TAIL=s: the software-pipelined 8-wave tail kernel (kernels_tail16.hip) instead of the 16-wave, stage-by-stage one (measured slower)
   int mid_waves = 0;     // SRCFD_MID_WAVES: other workgroup shapes of mid16 (4, 16: waves per workgroup at 32 pixels per wave); 0 = the shape mid_shape selects
+  int mid_order = 0;     // SRCFD_MID_ORDER=1: mid16's workgroups dispatched with output phases 0 / 3 and 1 / 2 alternating instead of phase by phase
   int tail_seg = 0;      // SRCFD_TAIL_SEG: segments per sample of the 16-bit tail (1, 2, 5, 10, 25); 0 = chosen per batch
   unsigned bits() const {
     return (enc16 ? 1u : 0u) | (mid16 ? 2u : 0u) | (dense1_16 ? 4u : 0u) | (enc32 ? 8u : 0u) | (skinny32 ? 16u : 0u) | (tail16s ? 32u : 0u) |
-           ((unsigned)mid_shape << 6) | ((unsigned)tail_seg << 8) | ((unsigned)mid_waves << 16);
+           ((unsigned)mid_shape << 6) | ((unsigned)tail_seg << 8) | ((unsigned)mid_waves << 16) | ((unsigned)mid_order << 24);
   }
-  bool all_default() const { return enc16 && mid16 && mid_shape == Switches().mid_shape && dense1_16 && enc32 && skinny32 && !tail16s && tail_seg == 0 && mid_waves == 0; }
+  bool all_default() const { return enc16 && mid16 && mid_shape == Switches().mid_shape && dense1_16 && enc32 && skinny32 && !tail16s && tail_seg == 0 && mid_waves == 0 && mid_order == Switches().mid_order; }
   static Switches from_env();
 };
 

@@ -305,6 +305,7 @@ Switches Switches::from_env() {
   w.enc32 = !on("SRCFD_NO_ENC32", false);
   w.skinny32 = !on("SRCFD_NO_DENSE_SKINNY", false);
   { const char* t = getenv("SRCFD_TAIL"); w.tail16s = t && t[0] == 's'; }
+  { const char* e = getenv("SRCFD_MID_ORDER"); if (e) w.mid_order = atoi(e) == 1 ? 1 : 0; }
   { const char* e = getenv("SRCFD_MID_WAVES"); const int v = e ? atoi(e) : 0; w.mid_waves = (v == 4 || v == 16) ? v : 0; }
   const char* e = getenv("SRCFD_TAIL_SEG");
   const int seg = e ? atoi(e) : 0;

@@ -462,6 +462,7 @@ int fused_forward(Model& m, const float* x_dev, int n, const float* aff_in, cons
       mp.w1f = P.d_w1f;
       mp.b1f = P.d_midb + 128;
       mp.ablate = 0;
+      mp.order = m.sw.mid_order;
       mp.prof = nullptr;
 #ifdef SRCFD_DIAG
       { static const int abl = [] { const char* e = getenv("SRCFD_MID_ABLATE"); return e ? atoi(e) : 0; }(); mp.ablate = abl; }

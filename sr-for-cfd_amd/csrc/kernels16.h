@@ -60,6 +60,8 @@ struct MidParams {
   const float* b0f;        // ConvT#0 bias as accumulator init [m-tile 4][lane half 2][16]
   const void* w1f;         // ConvT#1 A operands [m-tile 8][k-step 8][64 lanes] x 16 B, k in accumulator order
   const float* b1f;        // ConvT#1 bias as accumulator init [channel half 2][lane half 2][16]
+  int nblk[4];             // workgroups per output phase (filled by launch_mid16)
+  int order;               // 0: phase by phase; 1: phases 0 / 3 and 1 / 2 alternating (SRCFD_MID_ORDER, A/B)
   int ablate;              // diagnostic (SRCFD_MID_ABLATE): 1 no main-loop MFMA, 2 no ConvT#1 stage, 4 no operand loads, 8 no global stores, 16 no ConvT#1 swish
   unsigned long long* prof;  // diagnostic (SRCFD_MID_PROF, DIAG builds): per phase [4][6]: workgroups, cycles entry -> tables, -> first stage ready, main loop, ConvT#0 swish, ConvT#1 stage; else null
 };

@@ -4,14 +4,16 @@
 // Why not the generic implicit GEMM: measured on MI355X it spent ~0.45 ms/batch on these two
 // layers, bound by re-fetching the same input pixels from beyond L2 once per kernel tap, and by
 // writing / re-reading the 25x25x128 activation.  Here
-//   * ConvT#0 is split into its four output phases (blockIdx.y); a workgroup owns 128 output
-//     pixels of one phase and stages the contiguous slab of input pixels they touch ("patch",
-//     <= 176 pixels) in LDS once per 64-channel chunk; every tap then gathers its B operand from
-//     LDS with a per-lane row index, so the input is read from memory once, not once per tap;
-//   * a wave owns 32 pixels x all 128 channels (4 accumulator tiles), so after bias + swish the
-//     accumulators, packed to 16 bits, ARE the B operands of ConvT#1 (k order permuted on the
-//     host to the accumulator's register order): 64 more MFMAs per wave produce the four 2x2 taps
-//     x 64 channels, and only the 50x50x64 result goes to HBM.
+//   * ConvT#0 is split into its four output phases; a workgroup owns 256 (or 512) consecutive output
+//     pixels of one phase and stages the contiguous slab of input pixels they touch ("patch") in LDS
+//     once per 64-channel chunk; every tap then gathers its B operand from LDS with a per-lane row
+//     index, so the input is read from memory once per phase, not once per tap;
+//   * a wave owns 32 or 64 pixels (PT = 1 or 2 pixel tiles) x all 128 channels, so after bias + swish
+//     the accumulators, packed to 16 bits, ARE the B operands of ConvT#1 (k order permuted on the
+//     host to the accumulator's register order): 64 more MFMAs per pixel tile produce the four 2x2
+//     taps x 64 channels, and only the 50x50x64 result goes to HBM;
+//   * workgroup shapes: 4 waves x 64 pixels, two workgroups per CU (shipped);
+//     8 x 64, one per CU, three weight tiles in flight; 8 x 32, two per CU (rounds 1-2).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -48,7 +50,7 @@ template <int NW, int PT = 1> struct MidCfg {
   static constexpr int T1_END = W1_BYTES + NW * 32 * 144;       // ConvT#1 stage: its operands (8 KB tiles) + per-wave store tiles
   static constexpr int OFF_META = MAIN_END > T1_END ? MAIN_END : T1_END;
   static constexpr int LDS = OFF_META + 3 * PX * 4;
-  static_assert(PX <= 64 * NW * PT && (PT == 1 || PT == 2), "row tables are filled by one or two passes of the workgroup");
+  static_assert(PT == 1 || PT == 2, "one or two 32-pixel tiles per wave");
   static constexpr int NTHR = 64 * NW;
   static constexpr int WCH = 1024 / NTHR;               // weight-tile 16-byte chunks per thread
   static constexpr int PCH = (PATCH * 8 + NTHR - 1) / NTHR;  // patch chunks per thread
@@ -66,7 +68,27 @@ __global__ void __launch_bounds__(64 * NW, PT == 2 ? 2 : (NW == 8 ? 4 : 1)) mid1
   int* row_mx = row_my + C::PX;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), h = lane >> 5, l31 = lane & 31;
-  const int phase = blockIdx.y, blk = blockIdx.x;
+  // linear workgroup id -> (output phase, block of the phase).  order 0: phase by phase, longest first (phase 0: four taps ... phase 3: one).
+  // order 1: phases 0 and 3 alternate, then 1 and 2: the workgroups that start together then reach their store phase at different times.
+  int phase = 0, blk = 0;
+  {
+    int id = blockIdx.x;
+    const int nb0 = p.nblk[0], nb1 = p.nblk[1], nb2 = p.nblk[2], nb3 = p.nblk[3];
+    if (p.order == 0) {
+      if (id < nb0) { phase = 0; blk = id; }
+      else if (id < nb0 + nb1) { phase = 1; blk = id - nb0; }
+      else if (id < nb0 + nb1 + nb2) { phase = 2; blk = id - nb0 - nb1; }
+      else { phase = 3; blk = id - nb0 - nb1 - nb2; }
+    } else {
+      const int n03 = min(nb0, nb3), n12 = min(nb1, nb2);
+      if (id < 2 * n03) { phase = (id & 1) ? 3 : 0; blk = id >> 1; }
+      else if ((id -= 2 * n03) < nb0 - n03) { phase = 0; blk = n03 + id; }
+      else if ((id -= nb0 - n03) < nb3 - n03) { phase = 3; blk = n03 + id; }
+      else if ((id -= nb3 - n03) < 2 * n12) { phase = (id & 1) ? 2 : 1; blk = id >> 1; }
+      else if ((id -= 2 * n12) < nb1 - n12) { phase = 1; blk = n12 + id; }
+      else { phase = 2; blk = n12 + id - (nb1 - n12); }
+    }
+  }
 #ifdef SRCFD_DIAG
   unsigned long long tstamp[6], t_sync = 0, t_issue = 0, t_mma = 0, t_a = 0, t_b = 0;
   tstamp[0] = __builtin_amdgcn_s_memtime();
@@ -410,8 +432,11 @@ static hipError_t launch_mid16_nw(const MidParams& p, hipStream_t s) {
   void (*fn)(MidParams) = mid16<F16, NW, PT>;
   hipError_t e = lds_attr_once(reinterpret_cast<const void*>(fn), C::LDS);
   if (e != hipSuccess) return e;
-  const int blocks = (p.n * 169 + C::PX - 1) / C::PX;  // the largest phase (13x13 pixels per sample)
-  hipLaunchKernelGGL(fn, dim3(blocks, 4), dim3(C::NTHR), C::LDS, s, p);
+  MidParams q = p;
+  const int per[4] = {169, 156, 156, 144};   // pixels per sample and output phase (13x13, 13x12, 12x13, 12x12)
+  int total = 0;
+  for (int ph = 0; ph < 4; ++ph) { q.nblk[ph] = (p.n * per[ph] + C::PX - 1) / C::PX; total += q.nblk[ph]; }
+  hipLaunchKernelGGL(fn, dim3(total), dim3(C::NTHR), C::LDS, s, q);
   return hipGetLastError();
 }
 
