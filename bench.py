@@ -593,13 +593,43 @@ def dry_run(args, env):
         dist.all_reduce(counts)
         dist.all_reduce(fail, op=dist.ReduceOp.MAX)
     per_rank_256 = 256 // world if 256 % world == 0 else 0
+    budget = None
+    if rank == 0:
+        # What the N ranks of one host would hold: every rank reserves the workspaces of every precision its legs use and keeps its
+        # input / result buffers; rank 0 alone runs the host_io and CPU legs.  Sizes come from the library (srcfd_model_footprint on a
+        # host-only handle: nothing is allocated) and are set against the host's memory and one MI355X's 288 GB.
+        try:
+            srcfd = importlib.import_module("sr-for-cfd_amd")
+            synth = importlib.import_module("sr-for-cfd_amd.synth")
+            enc_w = srcfd.SRModel.load_h5(ENCODER_H5, None, device=-1).weights()
+            mdl = srcfd.SRModel.from_weights(enc_w, synth.synthetic_decoder_weights(1), device=-1)
+            n = 3 * args.fields
+            tile_n = int(counts.max().item()) if world > 1 else 48
+            legs = {"headline_bf16": mdl.footprint(n, "bf16"), "parity_fp32": mdl.footprint(n, "fp32"), "tiled_f16": mdl.footprint(tile_n, "f16")}
+            dev = sum(v["device_workspace"] for v in legs.values()) + 3 * legs["parity_fp32"]["device_weights"]
+            dev += n * (100 * 4 + 16) + n * 160000 * 4     # the rank's resident inputs + one f32 result buffer shared by the legs
+            dev += legs["headline_bf16"]["device_host_entry_staging"]          # host_io (rank 0): staging of the host-buffer entry
+            host_rank0 = 2 * legs["headline_bf16"]["host_result"]               # host_io: one result from the page-locked pool + one pageable array
+            host_every = n * (100 * 4 + 16)                                      # inputs kept on the host
+            runtime_per_process = 4 << 30                                         # torch + HIP runtime + code objects, measured ~3 GB resident
+            mem_total = None
+            for ln in open("/proc/meminfo"):
+                if ln.startswith("MemTotal:"):
+                    mem_total = int(ln.split()[1]) * 1024
+            host_all = world * (host_every + runtime_per_process) + host_rank0
+            budget = {"per_rank_device_bytes": int(dev), "device_capacity_bytes": 288 * 10**9, "host_bytes_all_ranks": int(host_all),
+                      "host_pinned_bytes_rank0": int(legs["headline_bf16"]["host_result"]), "host_mem_total_bytes": mem_total,
+                      "fits": bool(dev < 288 * 10**9 and (mem_total is None or host_all < mem_total)), "legs": legs,
+                      "not_counted": "the trainers of the train leg (f32 activations of a micro-batch of 8-32 samples: < 2 GB per rank)"}
+        except Exception as e:   # noqa: BLE001 -- the rehearsal must not die on an estimate
+            budget = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         print(json.dumps({"metric": "SR fields/sec (10x10->400x400, 3-ch) @batch256", "value": None, "unit": "fields/s", "dry_run": True,
                           "n_gpus": world, "world_size_reported": dist.get_world_size() if world > 1 else 1, "steps": args.steps,
                           "warmup": args.warmup, "max_over_ranks": t, "min_over_ranks": tmin, "tile_samples_covered": int(counts.sum().item()),
                           "tile_samples_per_rank": [int(c) for c in counts], "fields_total": args.fields * world,
                           "train": {"global_batch": 8 * world, "strong": {"global_batch": 256, "samples_per_rank": per_rank_256}},
-                          "leg_failed_somewhere": bool(fail.item()), "env": env}))
+                          "leg_failed_somewhere": bool(fail.item()), "budget": budget, "env": env}))
     if world > 1:
         dist.destroy_process_group()
 

@@ -105,6 +105,12 @@ int srcfd_model_get_precision(const srcfd_model* m);
  * every forward reserves what it needs itself.  The reference pays the equivalent cost inside its first
  * `predict` (graph tracing, PyCFD_ML_accelerated.py:858). */
 int srcfd_model_reserve(srcfd_model* m, int n);
+/* What an n-sample forward at `precision` keeps allocated, WITHOUT allocating anything (works on a host-only handle): bytes[0] device
+ * activation workspace (what srcfd_model_reserve reserves), bytes[1] device weights and operand packs (upper bound), bytes[2] device
+ * staging of the host-buffer entry (srcfd_predict), bytes[3] host bytes of one result of the call (page-locked when it comes from
+ * srcfd_host_alloc).  For capacity planning of several ranks on one host (bench.py's dry run); the reference has no counterpart
+ * (TensorFlow grows its arena on demand, PyCFD_ML_accelerated.py:858). */
+int srcfd_model_footprint(const srcfd_model* m, int n, int precision, size_t bytes[4]);
 /* 1 when the bf16/f16 fused decoder_400 kernels apply to this layer graph. */
 int srcfd_model_has_fused_path(const srcfd_model* m);
 

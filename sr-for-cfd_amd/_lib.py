@@ -99,6 +99,7 @@ _protos = {
     "srcfd_predict": (C.c_int, [_p, _p, C.c_int, _p, _p, _p, C.c_int, C.POINTER(C.c_int64)]),
     "srcfd_predict_device": (C.c_int, [_p, _p, C.c_int, _p, _p, _p, C.c_int, C.c_int, _p, _p]),
     "srcfd_model_workspace": (C.c_int, [_p, C.c_int, C.POINTER(_sz)]),
+    "srcfd_model_footprint": (C.c_int, [_p, C.c_int, C.c_int, C.POINTER(_sz)]),
     "srcfd_model_set_profiling": (C.c_int, [_p, C.c_int]),
     "srcfd_model_get_profile": (C.c_int, [_p, C.c_char_p, _sz, C.POINTER(C.c_float), C.POINTER(C.c_int), C.c_int]),
     "srcfd_model_debug_activation": (C.c_int, [_p, C.c_int, _p, _sz]),

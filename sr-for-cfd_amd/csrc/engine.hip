@@ -920,6 +920,32 @@ int srcfd_model_workspace(srcfd_model* m, int n, size_t* bytes) {
   return chunk;
 }
 
+int srcfd_model_footprint(const srcfd_model* m, int n, int precision, size_t bytes[4]) {
+  if (!m || !bytes || n < 0 || precision < 0 || precision > SRCFD_PREC_F16) { set_error("bad arguments"); return SRCFD_EINVAL; }
+  const srcfd::Model& mm = *M(m);
+  const bool lowp = precision == SRCFD_PREC_BF16 || precision == SRCFD_PREC_F16;
+  if (lowp && !mm.has_fused) { set_error("bf16/f16 precision needs the encoder_10+decoder_400 layer graph"); return SRCFD_EINVAL; }
+  int shp_in[3] = {0, 0, 0}, shp_out[3] = {0, 0, 0};
+  (void)srcfd_model_input_shape(m, shp_in);
+  (void)srcfd_model_output_shape(m, shp_out);
+  const size_t in_elems = (size_t)shp_in[0] * shp_in[1] * shp_in[2], out_elems = (size_t)shp_out[0] * shp_out[1] * shp_out[2];
+  size_t params = 0;
+  for (const auto& L : mm.desc.layers) params += L.kernel.size() + L.bias.size();
+  if (lowp) {
+    const size_t want = (size_t)std::min(n, 1024);
+    bytes[0] = want ? 2 * want * 160000 * sizeof(uint16_t) + 16 * want * 128 * sizeof(float) : 0;   // fused_reserve: two activation buffers + the dense split-K slabs
+    bytes[1] = params * (sizeof(float) + 2 * sizeof(uint16_t));   // f32 weights + the 16-bit GEMM layout + fragment re-orderings (upper bound: every layer twice)
+  } else {
+    const int chunk = n ? std::min(n, mm.chunk_cap()) : 0;
+    bytes[0] = 2 * (size_t)chunk * mm.max_act_elems() * sizeof(float);
+    bytes[1] = params * sizeof(float) * 2;   // packed weights + the per-layer operand orders of the fused f32 kernels (upper bound)
+  }
+  const size_t stage = (size_t)std::min(n, 256);
+  bytes[2] = stage * (in_elems + 2 * out_elems + 4) * sizeof(float);   // predict_host: input, two result buffers, affine pairs
+  bytes[3] = (size_t)n * out_elems * sizeof(float);                    // what ONE host result of the call takes (pool buffer or caller's array)
+  return SRCFD_OK;
+}
+
 int srcfd_model_set_profiling(srcfd_model* m, int enable) {
   if (!m) { set_error("null model"); return SRCFD_EINVAL; }
   M(m)->profiling = enable != 0;

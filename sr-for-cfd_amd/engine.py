@@ -227,6 +227,15 @@ class SRModel:
         """Allocate / pack now what the first n-sample forward at the current precision would set up lazily."""
         L.check(L.lib.srcfd_model_reserve(self._h, int(n)))
 
+    def footprint(self, n: int, precision: Optional[str] = None) -> dict:
+        """Bytes an n-sample forward keeps allocated, computed without allocating (srcfd_model_footprint; works on a host-only
+        handle): device activation workspace, device weights / operand packs (upper bound), device staging of the host-buffer
+        entry, host bytes of one result."""
+        arr = (C.c_size_t * 4)()
+        prec = PRECISIONS[precision] if precision is not None else L.check(L.lib.srcfd_model_get_precision(self._h))
+        L.check(L.lib.srcfd_model_footprint(self._h, int(n), prec, arr))
+        return {"device_workspace": int(arr[0]), "device_weights": int(arr[1]), "device_host_entry_staging": int(arr[2]), "host_result": int(arr[3])}
+
     def layers(self) -> List[dict]:
         out = []
         for i in range(L.check(L.lib.srcfd_model_num_layers(self._h))):

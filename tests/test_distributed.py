@@ -147,6 +147,15 @@ def test_bench_eight_rank_rehearsal():
     assert r["tile_samples_per_rank"] == [6] * 8 and r["tile_samples_covered"] == 48
     assert r["train"]["global_batch"] == 64 and r["train"]["strong"] == {"global_batch": 256, "samples_per_rank": 32}
     assert r["max_over_ranks"] == 8.0 and r["min_over_ranks"] == 1.0 and r["leg_failed_somewhere"] is False
+    # capacity: what eight ranks reserve (library-side sizes, nothing allocated) against this host's memory and one GPU's 288 GB
+    b = r["budget"]
+    assert "error" not in b, b
+    assert b["fits"] is True and 1e9 < b["per_rank_device_bytes"] < 20e9, b
+    legs = b["legs"]
+    assert legs["headline_bf16"]["device_workspace"] == 2 * 768 * 160000 * 2 + 16 * 768 * 128 * 4
+    assert legs["headline_bf16"]["host_result"] == 768 * 160000 * 4 == b["host_pinned_bytes_rank0"]
+    assert legs["parity_fp32"]["device_workspace"] == 2 * 768 * 160000 * 4        # ConvT#1's output is the largest tensor the f32 path materialises
+    assert legs["tiled_f16"]["device_workspace"] == 2 * 6 * 160000 * 2 + 16 * 6 * 128 * 4
     rc, recs, err = _run_bench(["--gpus", "8", "--steps", "3", "--warmup", "1"], {"SRCFD_BENCH_DRYRUN": "1", "SRCFD_BENCH_DRYRUN_FAIL_RANK": "5"})
     assert rc == 0 and recs[0]["leg_failed_somewhere"] is True
 
