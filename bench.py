@@ -379,7 +379,7 @@ class Job:
                "ms_per_step": round(ms, 4), "steps": steps, "dtype": precision, "out_dtype": out_dtype,
                "ms_per_step_rank_min_max": list(self.last_rank_ms), "untimed_pre_warm_ms": PRE_WARM_MS,
                "tflops_model": round(2.0 * MACS_PER_SAMPLE * self.n * self.world / (ms * 1e-3) / 1e12, 2),
-               "nonfinite": int(self.bad.item())}
+               "nonfinite": int(self.bad.item()), "last_plan": self.model.last_plan()}   # which kernels the timed calls ran (srcfd_model_last_plan)
         if self.rank == 0:
             kernels = self.kernel_profile(step, max(3, min(steps, 10)))
             tot = sum(kernels.values())
@@ -742,7 +742,7 @@ def main():
                        "parallelism": f"sample-sharded x{job.world}, no collective", "backend": job.backend if job.world > 1 else None},
             "tflops_model": head["tflops_model"], "nonfinite": head["nonfinite"],
             "kernels_ms": head.get("kernels_ms"), "kernels_ms_sum": head.get("kernels_ms_sum"), "launch_gap_ms": head.get("launch_gap_ms"),
-            "roofline": head.get("roofline"),
+            "roofline": head.get("roofline"), "last_plan": head.get("last_plan"),
             "cpu_baseline": cpu,
             "parity_path": parity, "train": train, "tiled": tiled, "host_io": host_io,
             "ms_per_step_rank_min_max": head.get("ms_per_step_rank_min_max"), "untimed_pre_warm_ms": head.get("untimed_pre_warm_ms"),

@@ -236,6 +236,34 @@ def test_reserve_is_the_set_up_a_first_call_would_do(srcfd, enc_weights, dec_wei
 
 
 @pytest.mark.gpu
+def test_footprint_is_what_reserve_allocates(srcfd, enc_weights, dec_weights):
+    """srcfd_model_footprint computes sizes without allocating (bench.py's capacity estimate for N ranks on one host rests on it):
+    the device memory that reserve(n) actually takes is its activation workspace, up to the allocator's granularity, and the
+    host-only handle gives the same numbers as the device handle."""
+    require_gpu(srcfd)
+    import torch
+    host_only = srcfd.SRModel.from_weights(enc_weights, dec_weights, device=-1)
+    for prec, n in (("bf16", 768), ("fp32", 768), ("f16", 48)):
+        m = srcfd.SRModel.from_weights(enc_weights, dec_weights, device=0)
+        m.precision = prec
+        fp = m.footprint(n)
+        assert fp == host_only.footprint(n, prec)
+        m.reserve(1)                      # operand packs, streams, events: everything that does not scale with n
+        torch.cuda.synchronize()
+        free0, _ = torch.cuda.mem_get_info()
+        m.reserve(n)
+        torch.cuda.synchronize()
+        free1, _ = torch.cuda.mem_get_info()
+        took = free0 - free1
+        one = m.footprint(1)["device_workspace"]
+        want = fp["device_workspace"] - one
+        print(f"{prec} n={n}: reserve took {took / 1e6:.1f} MB, footprint says {want / 1e6:.1f} MB (+ {one / 1e6:.2f} for n = 1)")
+        assert abs(took - want) <= 0.02 * want + (64 << 20), (prec, took, want)    # hipMalloc rounds to its pool granularity
+        assert fp["host_result"] == n * 160000 * 4
+        del m
+
+
+@pytest.mark.gpu
 def test_config3_end_to_end_from_a_coarse_bfs_solve_made_here(srcfd, decoder_h5, coarse_cases):
     """BASELINE config 3 without any stored input: coarse backward-facing-step solve (csrc/coarse_solver.cpp, the reference's
     __main__ settings) -> ml_super_resolution with aspect-ratio correction and blend 0.3.  The coarse field is within the

@@ -115,6 +115,8 @@ def test_the_workgroup_shapes_of_the_fused_middle_agree_bit_for_bit(srcfd, enc_w
     for n in (1, 3, 7, 50, 303):
         x = rng.standard_normal((n, 10, 10, 1)).astype(np.float32)
         outs = {}
+        monkeypatch.delenv("SRCFD_MID_ORDER", raising=False)
+        monkeypatch.delenv("SRCFD_MID_WAVES", raising=False)
         for mid in ("1", "2", "3"):
             monkeypatch.setenv("SRCFD_MID", mid)
             outs[mid] = m.predict(x).copy()
@@ -124,6 +126,15 @@ def test_the_workgroup_shapes_of_the_fused_middle_agree_bit_for_bit(srcfd, enc_w
         if n <= 50:
             assert np.array_equal(outs["1a"], outs["2a"]) and np.array_equal(outs["1a"], outs["3a"]), f"n={n}: ConvT#1 activations differ"
         assert np.array_equal(outs["1"], outs["2"]) and np.array_equal(outs["1"], outs["3"]), f"n={n}"
+        # the remaining diagnostic shapes / orders of the same kernel: 4 and 16 waves at 32 pixels per wave, phases dispatched alternately
+        monkeypatch.setenv("SRCFD_MID_ORDER", "1")
+        assert np.array_equal(m.predict(x), outs["1"]), f"n={n}: SRCFD_MID_ORDER=1"
+        monkeypatch.delenv("SRCFD_MID_ORDER")
+        for w, name in (("4", "mid16_4x32"), ("16", "mid16_16x32")):
+            monkeypatch.setenv("SRCFD_MID_WAVES", w)
+            assert np.array_equal(m.predict(x), outs["1"]), f"n={n}: SRCFD_MID_WAVES={w}"
+            assert m.last_plan()["middle"] == name
+        monkeypatch.delenv("SRCFD_MID_WAVES")
 
 
 @pytest.mark.parametrize("kind", ["bf16", "f16"])
