@@ -115,9 +115,15 @@ struct Tail32Params {
   unsigned long long* nonfinite;
   int out_dtype;
   int seg;            // segments per sample (a divisor of 2H)
+  // training forward (train.hip): out = two_scale * (image - target) in f32, sum of squared errors of workgroup b in
+  // sse_partial[b] (tail32_blocks() of them); aff_out / nan_guard are ignored.  null: inference.
+  const float* target = nullptr;
+  float two_scale = 0.f;
+  double* sse_partial = nullptr;
 };
 hipError_t launch_tail32(const Tail32Params& p, int num_cus, hipStream_t s);
 int tail32_segments(int n, int H, int num_cus);
+int tail32_blocks(int n, int seg, int num_cus);   // workgroups launch_tail32 starts
 
 // Last layer + de-standardise + NaN guard + output cast in one kernel, for the layers gemm_fuses_finalize() accepts.
 bool gemm_fuses_finalize(const GemmDesc& d);

@@ -86,7 +86,10 @@ struct Strip {
   int warm;    // warm-up strip of a segment: computed for the ring only, its rows belong to the previous segment
 };
 
-template <int OUT>  // 0 f32, 1 bf16, 2 f16
+// TRAIN (train.hip, forward pass of a training step): the epilogue turns the image into the loss gradient instead of
+// de-standardising it -- out = dpred = two_scale * (pred - target), and every workgroup leaves the sum of its squared
+// errors (float64, fixed order: the row -> workgroup assignment is static) in sse_partial[blockIdx.x].
+template <int OUT, bool TRAIN>  // OUT: 0 f32, 1 bf16, 2 f16
 __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, rg = lane >> 4;
@@ -133,6 +136,7 @@ __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
   const int d_r = (dbc & 1) ? ((dbc >> 1) + 2) * 16 : 4 * R_PLANE + ((dbc >> 1) + 1) * 16;              // column X0 + 4
   const f32x4* wk = reinterpret_cast<const f32x4*>(smem + R_WC);   // [tap][half]
   unsigned bad_total = 0;
+  double sse = 0.0;
 
   // ---- job iterator: virtual samples blockIdx.x + j * gridDim.x, each a run of strips.  Plain scalars kept wave-uniform
   // (readfirstlane) so that the whole bookkeeping runs on the scalar unit.
@@ -260,10 +264,13 @@ __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
     };
     // the first layer's MFMAs between the three window rows of the output conv (one copy of the block per tap row: selecting
     // the weights per k-step instead costs 32 vector instructions per item)
+    const size_t o_row = ((size_t)d_smp * OHs + d_yl) * OW;
+    f32x4 tgt = {0.f, 0.f, 0.f, 0.f};
     auto front = [&](auto TY1) {
       layer1(TY1, std::integral_constant<int, 0>{}, std::integral_constant<int, 6>{});
       window_row(std::integral_constant<int, 0>{}, ro0);
       load_x(ldx, xn);   // behind the asm of window_row (a memory clobber): cannot be hoisted above the first MFMA
+      if (TRAIN) tgt = *reinterpret_cast<const f32x4*>(p.target + o_row + 4 * (d_lane ? db : 0));
       layer1(TY1, std::integral_constant<int, 6>{}, std::integral_constant<int, 11>{});
       window_row(std::integral_constant<int, 1>{}, ro1);
       layer1(TY1, std::integral_constant<int, 11>{}, std::integral_constant<int, 16>{});
@@ -277,15 +284,20 @@ __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
 #pragma unroll
       for (int o = 0; o < 4; ++o) {
         float t = acc[o][0] + acc[o][1];
-        if (p.aff_out) t = __fadd_rn(__fmul_rn(t, d_sd), d_mean);
-        if (p.nan_guard) {
+        if (TRAIN) {
+          const float e = t - tgt[o];
+          if (st_on) sse += (double)e * (double)e;
+          t = p.two_scale * e;
+        }
+        if (!TRAIN && p.aff_out) t = __fadd_rn(__fmul_rn(t, d_sd), d_mean);
+        if (!TRAIN && p.nan_guard) {
           const bool bad = st_on && !(fabsf(t) <= 3.402823466e38f);
           bad_total += (unsigned)__popcll(__ballot(bad));
           t = bad ? 0.f : t;
         }
         v[o] = t;
       }
-      const size_t o0 = ((size_t)d_smp * OHs + d_yl) * OW + 4 * (d_lane ? db : 0);
+      const size_t o0 = o_row + 4 * (d_lane ? db : 0);
       if (st_on) {
         if (OUT == 0) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + o0) = f32x4{v[0], v[1], v[2], v[3]};
         else {
@@ -341,19 +353,32 @@ __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
     ring0 += 4;
     ring0 = ring0 >= R_ROWS ? ring0 - R_ROWS : ring0;
   }
-  if (p.nan_guard && p.nonfinite && bad_total && lane == 0) atomicAdd(p.nonfinite, (unsigned long long)bad_total);
+  if (!TRAIN && p.nan_guard && p.nonfinite && bad_total && lane == 0) atomicAdd(p.nonfinite, (unsigned long long)bad_total);
+  if (TRAIN) {   // lanes -> waves -> workgroup, always in the same order
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sse += __shfl_xor(sse, o, 64);
+    __syncthreads();   // the ring is dead: its first bytes carry the eight wave sums
+    double* red = reinterpret_cast<double*>(smem);
+    if (lane == 0) red[wave] = sse;
+    __syncthreads();
+    if (tid == 0) p.sse_partial[blockIdx.x] = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+  }
 }
 
 hipError_t launch_tail32(const Tail32Params& p, int num_cus, hipStream_t s) {
   if (p.n == 0) return hipSuccess;
-  void (*fn)(Tail32Params) = p.out_dtype == SRCFD_F32 ? tail32<0> : (p.out_dtype == SRCFD_BF16 ? tail32<1> : tail32<2>);
+  void (*fn)(Tail32Params) = p.target ? tail32<0, true>
+                             : (p.out_dtype == SRCFD_F32 ? tail32<0, false> : (p.out_dtype == SRCFD_BF16 ? tail32<1, false> : tail32<2, false>));
+  if (p.target && (p.out_dtype != SRCFD_F32 || !p.sse_partial)) return hipErrorInvalidValue;
   hipError_t e = lds_attr_once(reinterpret_cast<const void*>(fn), T32_LDS);
   if (e != hipSuccess) return e;
   const int S = p.seg > 1 ? p.seg : 1;
-  const int blocks = (int)std::min<int64_t>((int64_t)p.n * S, num_cus);
+  const int blocks = tail32_blocks(p.n, S, num_cus);
   hipLaunchKernelGGL(fn, dim3(blocks), dim3(512), T32_LDS, s, p);
   return hipGetLastError();
 }
+
+int tail32_blocks(int n, int seg, int num_cus) { return (int)std::min<int64_t>((int64_t)n * (seg > 1 ? seg : 1), num_cus); }
 
 // Segments per sample for a batch of n samples of 2H strips each: the busiest workgroup walks ceil(n S / CUs) virtual
 // samples of 2H/S (+1 warm-up) strips, + 2 rounds of pipeline depth; more segments must buy 10 % to be taken.

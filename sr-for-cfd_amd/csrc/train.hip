@@ -26,6 +26,7 @@
 
 #include "act_device.h"
 #include "engine.h"
+#include "train_tail.h"
 
 namespace srcfd {
 
@@ -86,10 +87,17 @@ __global__ void __launch_bounds__(256) sum_partials_f64(const double* __restrict
   if (threadIdx.x == 0) *out += red[0];
 }
 
-// dst[i] = map[i] > 0 ? src[map[i]-1] : 0   (flat params -> packed operand buffers)
-__global__ void __launch_bounds__(256) gather_pack_f32(const float* __restrict__ src, const int* __restrict__ map, float* __restrict__ dst, int64_t n) {
+// dst[i] = map[i] > 0 ? src[map[i]-1] : 0   (flat params -> packed operand buffers); slots from scale_begin on carry a factor
+// (the fused tail's operands: log2(e) folded into the swish layers, train_tail.h)
+__global__ void __launch_bounds__(256) gather_pack_f32(const float* __restrict__ src, const int* __restrict__ map, float* __restrict__ dst, int64_t n,
+                                                        const float* __restrict__ scale, int64_t scale_begin) {
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) { int k = map[i]; dst[i] = k > 0 ? src[k - 1] : 0.f; }
+  if (i < n) {
+    int k = map[i];
+    float v = k > 0 ? src[k - 1] : 0.f;
+    if (i >= scale_begin) v *= scale[i - scale_begin];
+    dst[i] = v;
+  }
 }
 
 // Keras Adam (sr-ae-conv.ipynb:c556 defaults): m,v moments, alpha_t = lr sqrt(1-b2^t)/(1-b1^t), p -= alpha_t m/(sqrt(v)+eps)
@@ -486,6 +494,14 @@ struct Trainer {
   float* d_part = nullptr; size_t part_elems = 0;
   float* d_splitk = nullptr; size_t splitk_floats = 0;
   double* d_loss_partial = nullptr;
+  // The last four layers as two launches (train_tail.h): tail32<TRAIN> forward, tail_bwd32 backward.  SRCFD_TRAIN_TAIL=0: layer by layer.
+  TrainTailPlan tail;
+  bool use_tail = false;
+  int num_cus = 256;
+  size_t tail_pack_off = 0;          // the tail's operands sit behind the forward pack in d_pack
+  float* d_pack_scale = nullptr;     // factors of those slots
+  float* d_tail_slabs = nullptr;     // [num_cus][TT_PARAMS]
+  int* d_tail_gmap = nullptr;        // slab slot -> flat parameter + 1
   ~Trainer();
 };
 
@@ -500,7 +516,8 @@ Trainer::~Trainer() {
   for (hipEvent_t e : ev_dz) (void)hipEventDestroy(e);
   for (hipEvent_t e : ev_wg) (void)hipEventDestroy(e);
   for (void* p : {(void*)d_pack, (void*)d_pack_map, (void*)d_dpack, (void*)d_dpack_map, (void*)d_zero_bias, (void*)dbuf[0], (void*)dbuf[1],
-                  (void*)dbuf[2], (void*)d_part, (void*)d_loss_partial, (void*)d_splitk})
+                  (void*)dbuf[2], (void*)d_part, (void*)d_loss_partial, (void*)d_splitk, (void*)d_pack_scale, (void*)d_tail_slabs,
+                  (void*)d_tail_gmap})
     if (p) (void)hipFree(p);
   for (size_t i = 0; i < Z.size(); ++i) {
     if (Y[i] && Y[i] != Z[i]) (void)hipFree(Y[i]);
@@ -608,6 +625,27 @@ static int trainer_build(Trainer& t, const Model& model, int max_batch) {
   std::vector<Op> iops;
   std::vector<float> ipack;
   build_plan(im, iops, ipack);
+  // the fused tail's operands ride behind the forward pack, gathered by the same launch
+  t.num_cus = model.num_cus > 0 ? model.num_cus : 256;
+  {
+    std::vector<int> di; std::vector<size_t> ko, bo;
+    for (const LayerInfo& L : t.layers) { di.push_back(L.desc_index); ko.push_back(L.kernel_off); bo.push_back(L.bias_off); }
+    train_tail_plan(t.desc, di.data(), ko.data(), bo.data(), (int)t.layers.size(), t.tail);
+    const char* e = getenv("SRCFD_TRAIN_TAIL");
+    t.use_tail = t.tail.ok && !(e && atoi(e) == 0) && (uint64_t)max_batch * t.tail.H * t.tail.W * t.tail.H * t.tail.W < (1ull << 32);
+  }
+  while (ipack.size() % 64) ipack.push_back(0.f);
+  t.tail_pack_off = ipack.size();
+  if (t.use_tail) {
+    for (int k : t.tail.map) ipack.push_back((float)k);
+    HIPCHECK(hipMalloc(&t.d_pack_scale, t.tail.scale.size() * sizeof(float)));
+    HIPCHECK(hipMemcpy(t.d_pack_scale, t.tail.scale.data(), t.tail.scale.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHECK(hipMalloc(&t.d_tail_slabs, (size_t)t.num_cus * TT_PARAMS * sizeof(float)));
+    std::vector<int> gm(TT_PARAMS);
+    for (int i = 0; i < TT_PARAMS; ++i) gm[i] = (int)(t.tail.param_off + i + 1);
+    HIPCHECK(hipMalloc(&t.d_tail_gmap, TT_PARAMS * sizeof(int)));
+    HIPCHECK(hipMemcpy(t.d_tail_gmap, gm.data(), TT_PARAMS * sizeof(int), hipMemcpyHostToDevice));
+  }
   t.pack_elems = ipack.size();
   int rc = upload_map(ipack, &t.d_pack_map);
   if (rc) return rc;
@@ -711,11 +749,17 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
   HIPCHECK(hipSetDevice(t.device));
   auto grid = [](int64_t n_) { return dim3((unsigned)((n_ + 255) / 256)); };
   // 1. pack operands from the flat parameters
-  hipLaunchKernelGGL(gather_pack_f32, grid(t.pack_elems), dim3(256), 0, s, params, t.d_pack_map, t.d_pack, (int64_t)t.pack_elems);
-  if (t.dpack_elems) hipLaunchKernelGGL(gather_pack_f32, grid(t.dpack_elems), dim3(256), 0, s, params, t.d_dpack_map, t.d_dpack, (int64_t)t.dpack_elems);
-  // 2. forward, keeping Z (pre-activation) and Y (post) of every layer
+  hipLaunchKernelGGL(gather_pack_f32, grid(t.pack_elems), dim3(256), 0, s, params, t.d_pack_map, t.d_pack, (int64_t)t.pack_elems,
+                     (const float*)t.d_pack_scale, (int64_t)(t.use_tail ? t.tail_pack_off : t.pack_elems));
+  if (t.dpack_elems) hipLaunchKernelGGL(gather_pack_f32, grid(t.dpack_elems), dim3(256), 0, s, params, t.d_dpack_map, t.d_dpack, (int64_t)t.dpack_elems,
+                                        (const float*)nullptr, (int64_t)t.dpack_elems);
+  // 2. forward, keeping Z (pre-activation) and Y (post) of every layer; with the fused tail the last four layers are one
+  //    streaming launch that ends in the loss gradient (nothing of them is kept: tail_bwd32 recomputes what it needs)
+  const int L = (int)t.layers.size();
+  const int Lg = t.use_tail ? t.tail.first_layer : L;   // layers [0, Lg) run layer by layer
   for (size_t i = 0; i < t.ops.size();) {
     const TrainOp& op = t.ops[i];
+    if (op.layer >= Lg) break;
     GemmDesc ds[4];
     const float* Bs[4];
     const float* biases[4];
@@ -741,10 +785,23 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
     }
   }
   // 3. loss and its gradient (sr-ae-conv.ipynb:c314): sum of squared errors; dpred = 2 scale (pred - y)
-  const int L = (int)t.layers.size();
-  int64_t oe = (int64_t)n * t.layers[L - 1].out_elems;
-  int nb = (int)std::min<int64_t>(1024, (oe + 255) / 256);
-  hipLaunchKernelGGL(mse_grad_f32, dim3(nb), dim3(256), 0, s, t.Y[L - 1], y, t.dbuf[0], oe, loss_scale, t.d_loss_partial);
+  int nb;
+  const float* tp = t.d_pack + t.tail_pack_off;
+  if (t.use_tail) {
+    Tail32Params q;
+    q.in = t.Y[Lg - 1]; q.out = t.dbuf[1]; q.n = n; q.H = t.tail.H; q.W = t.tail.W;
+    q.w1f = tp + t.tail.t32_w1; q.b1 = tp + t.tail.t32_b1; q.w2f = tp + t.tail.t32_w2; q.b2 = tp + t.tail.t32_b2;
+    q.w3f = tp + t.tail.t32_w3; q.b3 = tp + t.tail.t32_b3; q.wc = tp + t.tail.t32_wc;
+    q.aff_out = nullptr; q.nan_guard = 0; q.nonfinite = nullptr; q.out_dtype = SRCFD_F32;
+    q.seg = tail32_segments(n, q.H, t.num_cus);
+    q.target = y; q.two_scale = 2.0f * loss_scale; q.sse_partial = t.d_loss_partial;
+    nb = tail32_blocks(n, q.seg, t.num_cus);
+    HIPCHECK(launch_tail32(q, t.num_cus, s));
+  } else {
+    int64_t oe = (int64_t)n * t.layers[L - 1].out_elems;
+    nb = (int)std::min<int64_t>(1024, (oe + 255) / 256);
+    hipLaunchKernelGGL(mse_grad_f32, dim3(nb), dim3(256), 0, s, t.Y[L - 1], y, t.dbuf[0], oe, loss_scale, t.d_loss_partial);
+  }
   if (sse_dev) hipLaunchKernelGGL(sum_partials_f64, dim3(1), dim3(256), 0, s, t.d_loss_partial, nb, sse_dev);
   // 4. backward.  Main stream: swish' -> data gradient -> swish' -> ... (the dependent chain); aux stream: the weight
   //    gradients, each waiting only for its layer's dZ.  dZ buffers rotate through a ring of three, so the data-gradient
@@ -756,7 +813,21 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
   for (auto& ft : ftab) ft.nops = 0;
   bool dz_done = false;  // the data-gradient GEMM below already multiplied by swish'(Z) of the layer it feeds (EpiAux mode 2)
   hipStream_t ws = t.overlap ? t.aux : s;
-  for (int li = L - 1; li >= 0; --li) {
+  if (t.use_tail) {      // every gradient of the last four layers + dZ of layer Lg - 1, from dpred (dbuf[1]) and that layer's Z / Y
+    TailBwdParams q;
+    q.y1 = t.Y[Lg - 1]; q.z1 = t.Z[Lg - 1]; q.dpred = t.dbuf[1]; q.dz1 = t.dbuf[0]; q.slabs = t.d_tail_slabs;
+    q.wf = tp + t.tail.wf; q.wb = tp + t.tail.wb; q.bias = tp + t.tail.bias;
+    q.n = n; q.H = t.tail.H; q.W = t.tail.W;
+    HIPCHECK(launch_tail_bwd32(q, t.num_cus, s));
+    dz_done = true;
+    FinishOp& fo = ftab[0].op[ftab[0].nops++];
+    fo.part = t.d_tail_slabs; fo.map = t.d_tail_gmap; fo.elems = TT_PARAMS; fo.nslices = tail_bwd32_blocks(n, q.H, q.W, t.num_cus);
+    fo.K = 0x7fffffff; fo.N = 1; fo.Npad = 1; fo.CO = 1;   // one column, no bias row: every slot is a parameter of its own
+    fo.groups = fo.nslices >= 256 ? 32 : (fo.nslices >= 64 ? 8 : (fo.nslices >= 8 ? 4 : 1));
+    fo.block0 = fblocks[0];
+    fblocks[0] += (TT_PARAMS + 256 / fo.groups - 1) / (256 / fo.groups);
+  }
+  for (int li = Lg - 1; li >= 0; --li) {
     float* dZ = t.dbuf[cur];
     int64_t e = (int64_t)n * t.layers[li].out_elems;
     if (t.layers[li].swish && !dz_done) hipLaunchKernelGGL(swish_bwd_f32, grid(e), dim3(256), 0, s, t.Z[li], dZ, e);
@@ -794,7 +865,7 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
       d.M = n * d.MH * d.MW;
       const int nxt = (cur + 1) % 3;
       // the ring slot about to be overwritten held dZ of layer li+2: its weight gradient must have read it
-      if (t.overlap && li + 2 <= L - 1) HIPCHECK(hipStreamWaitEvent(s, t.ev_wg[li + 2], 0));
+      if (t.overlap && li + 2 <= Lg - 1) HIPCHECK(hipStreamWaitEvent(s, t.ev_wg[li + 2], 0));
       EpiAux aux;
       if (t.fuse_epilogues && t.layers[li - 1].swish && gemm_supports_epi_aux(d)) { aux.mode = 2; aux.zaux = t.Z[li - 1]; dz_done = true; }
       HIPCHECK(launch_gemm_mfma(d, dZ, t.d_dpack + dg.w_off, t.d_zero_bias, t.dbuf[nxt], s, t.d_splitk, t.splitk_floats, false, aux));
