@@ -816,7 +816,7 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
   if (t.use_tail) {      // every gradient of the last four layers + dZ of layer Lg - 1, from dpred (dbuf[1]) and that layer's Z / Y
     TailBwdParams q;
     q.y1 = t.Y[Lg - 1]; q.z1 = t.Z[Lg - 1]; q.dpred = t.dbuf[1]; q.dz1 = t.dbuf[0]; q.slabs = t.d_tail_slabs;
-    q.wf = tp + t.tail.wf; q.wb = tp + t.tail.wb; q.bias = tp + t.tail.bias;
+    q.wf = tp + t.tail.wf; q.wb = tp + t.tail.wb; q.wt = tp + t.tail.wt; q.bias = tp + t.tail.bias;
     q.n = n; q.H = t.tail.H; q.W = t.tail.W;
     HIPCHECK(launch_tail_bwd32(q, t.num_cus, s));
     dz_done = true;

@@ -25,9 +25,11 @@ constexpr int TT_PARAMS = 10881;
 //   t32_* : the operands of tail32 (engine.hip, plan_tail32: log2(e) folded into w1 / biases, 1 / log2(e) into wc)
 //   wf    : unscaled forward A fragments  w1f[4][2][16][64] | w2f[4][8][64] | w3f[2][4][64]      (same lane maps as tail32)
 //   wb    : data-gradient A fragments     a1b[4][4][2][4][64] | a2b[4][2][4][64] | a3b[2][4][64] (train_tail.hip)
+//   wt    : the output conv as a banded 16 x 12 matrix, wt[3][64]
 //   bias  : b1[32] | b2[16] | b3[8] | wc[72] | bc[1]  (unscaled)
 constexpr int TT_WF = 4 * 2 * 16 * 64 + 4 * 8 * 64 + 2 * 4 * 64;   // 10752 floats
 constexpr int TT_WB = 4 * 4 * 8 * 64 + 4 * 2 * 4 * 64 + 2 * 4 * 64; // 10752
+constexpr int TT_WT = 3 * 64;                                       // Toeplitz fragments of the output conv (train_tail.hip)
 constexpr int TT_BIAS = 32 + 16 + 8 + 72 + 1;                       // 129 (padded to 192 in the pack)
 
 struct TrainTailPlan {
@@ -38,7 +40,7 @@ struct TrainTailPlan {
   // pack (floats, relative to the start of the tail's pack region): maps hold flat index + 1 (0: padding)
   std::vector<int> map;
   std::vector<float> scale;
-  size_t t32_w1 = 0, t32_b1 = 0, t32_w2 = 0, t32_b2 = 0, t32_w3 = 0, t32_b3 = 0, t32_wc = 0, wf = 0, wb = 0, bias = 0;
+  size_t t32_w1 = 0, t32_b1 = 0, t32_w2 = 0, t32_b2 = 0, t32_w3 = 0, t32_b3 = 0, t32_wc = 0, wf = 0, wb = 0, wt = 0, bias = 0;
 };
 // kernel_off / bias_off: flat offsets of the four layers' kernels and biases (train.hip, LayerInfo)
 void train_tail_plan(const ModelDesc& desc, const int* desc_index, const size_t* kernel_off, const size_t* bias_off, int n_compute_layers,
@@ -50,7 +52,7 @@ struct TailBwdParams {
   const float* dpred;   // (n, 8H, 8W): loss gradient
   float* dz1;           // out: (n, H, W, 64) gradient w.r.t. ConvT#1's pre-activation
   float* slabs;         // out: [tail_bwd32_blocks()][TT_PARAMS] weight-gradient partial sums, one slab per workgroup
-  const float* wf; const float* wb; const float* bias;
+  const float* wf; const float* wb; const float* wt; const float* bias;
   int n, H, W;
   unsigned magic_hw = 0, magic_w = 0;   // filled by launch_tail_bwd32: division by H W and by W as a multiply
 };

@@ -35,19 +35,23 @@ namespace srcfd {
 typedef float f4 __attribute__((ext_vector_type(4)));
 
 constexpr int TB_PITCH = 101;                       // dpred window image: [16 pixels][10 x 10], odd pitch
+constexpr int TB_YP = 68;                           // activation tile image: [16 pixels][64 channels + 4]
 constexpr int L_WF = 0;
 constexpr int L_WB = L_WF + TT_WF;                  // 10752
-constexpr int L_DP = L_WB + TT_WB;                  // 21504
-constexpr int L_TR = L_DP + 1664;                   // wave-private transposition images: 4 waves x 2 x 320 floats
-constexpr int L_RED = L_TR + 4 * 640;               // dY1 partial sums of the four taps: [wave][tile][lane] float4
-constexpr int L_END = L_RED + 4 * 4 * 64 * 4;       // 29824 floats
-constexpr int TB_LDS = L_END * 4;                   // 119296 B: one workgroup per CU
+constexpr int L_WT = L_WB + TT_WB;                  // 21504: Toeplitz fragments of the output conv, 3 k-steps
+constexpr int L_DP = L_WT + TT_WT;                  // 21696: two tile slots x 1664
+constexpr int L_Y1 = L_DP + 2 * 1664;               // two slots x 16 x 68
+constexpr int L_TR = L_Y1 + 2 * 16 * TB_YP;         // wave-private transposition images: 8 waves x 2 x 320 floats
+constexpr int L_RED = L_TR + 8 * 640;               // dY1 partial sums of the four taps: [slot][wave][tile][lane] float4
+constexpr int L_END = L_RED + 2 * 4 * 4 * 64 * 4;   // 40512 floats
+constexpr int TB_LDS = L_END * 4;                   // 162048 B: one workgroup per CU
 static_assert(TB_LDS <= 160 * 1024, "tail_bwd32 LDS budget");
 // end-of-kernel reduction images (the weight images are dead by then)
-constexpr int E_R40 = 0;                            // [wave][40 registers][lane]: dW3 (32) | dW4 (8)
-constexpr int E_R2 = 4 * 40 * 64;                   // [wave][132]: dWc 72 | db4 8 | db3 16 | pad 0 | db2 32 | dbc 1
-constexpr int E_R2S = 132;
-static_assert(E_R2 + 4 * E_R2S <= L_END, "reduction images fit");
+constexpr int E_RW = 44;                            // registers per wave: dW3 (32) | dW4 (8) | Toeplitz gradient of the output conv (4)
+constexpr int E_R40 = 0;                            // [wave][44][lane]
+constexpr int E_R2 = 8 * E_RW * 64;                 // [wave][64]: db4 8 | db3 16 | db2 32 | dbc 1
+constexpr int E_R2S = 64;
+static_assert(E_R2 + 8 * E_R2S <= L_TR && L_TR + 4 * 32 * 64 <= L_END, "reduction images fit below the parking area of ConvT#2's partial sums");
 
 __device__ __forceinline__ f4 mf(float a, float b, f4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -80,42 +84,50 @@ __device__ __forceinline__ float red16(float v) {   // over the 16 pixels of a l
   return v;
 }
 
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) tail_bwd32(TailBwdParams p) {
+// Eight waves: two tile slots x the four taps of ConvT#2; the two waves of a SIMD work on different tiles (one wave's LDS
+// round trips and vector work beside the other's matrix work).  256 registers per wave.
+__global__ void __launch_bounds__(512) tail_bwd32(TailBwdParams p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, g = lane >> 4, h = g & 1;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ty1 = wave >> 1, tx1 = wave & 1;
+  const int slot = wave >> 2, tap1 = wave & 3, ty1 = tap1 >> 1, tx1 = tap1 & 1, stid = tid & 255;
   const int H = p.H, W = p.W, HW = H * W, OW = 8 * W, OH = 8 * H;
   const int NP = p.n * HW, ntiles = (NP + 15) >> 4;
 
-  for (int i = tid; i < (TT_WF + TT_WB) / 4; i += 256)
-    reinterpret_cast<f4*>(sm)[i] = i < TT_WF / 4 ? reinterpret_cast<const f4*>(p.wf)[i] : reinterpret_cast<const f4*>(p.wb)[i - TT_WF / 4];
-  f4 bz2[2], bz3, bz4, wcr[9];
+  for (int i = tid; i < (TT_WF + TT_WB + TT_WT) / 4; i += 512) {
+    f4 v;
+    if (i < TT_WF / 4) v = reinterpret_cast<const f4*>(p.wf)[i];
+    else if (i < (TT_WF + TT_WB) / 4) v = reinterpret_cast<const f4*>(p.wb)[i - TT_WF / 4];
+    else v = reinterpret_cast<const f4*>(p.wt)[i - (TT_WF + TT_WB) / 4];
+    reinterpret_cast<f4*>(sm)[i] = v;
+  }
+  f4 bz2[2], bz3, bz4;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     bz2[0][i] = p.bias[4 * g + i]; bz2[1][i] = p.bias[16 + 4 * g + i];
     bz3[i] = p.bias[32 + 4 * g + i];
     bz4[i] = p.bias[48 + 4 * h + i];
   }
-#pragma unroll
-  for (int t = 0; t < 9; ++t)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) wcr[t][i] = p.bias[56 + t * 8 + 4 * h + i];
-
-  const float* w1f = sm + L_WF + wave * (2 * 16 * 64) + lane;     // [(t*16 + s) * 64]
+  const float* w1f = sm + L_WF + tap1 * (2 * 16 * 64) + lane;     // [(t*16 + s) * 64]
   const float* w2f = sm + L_WF + 8192 + lane;                     // [(tap2*8 + ks) * 64]
   const float* w3f = sm + L_WF + 8192 + 2048 + lane;              // [(u*4 + i) * 64]
-  const float* a1b = sm + L_WB + wave * (4 * 8 * 64) + lane;      // [((t*2 + c)*4 + i) * 64]
+  const float* a1b = sm + L_WB + tap1 * (4 * 8 * 64) + lane;      // [((t*2 + c)*4 + i) * 64]
   const float* a2b = sm + L_WB + 8192 + lane;                     // [((tap2*2 + t)*4 + i) * 64]
   const float* a3b = sm + L_WB + 8192 + 2048 + lane;              // [(u*4 + i) * 64]
+  const float* wtp = sm + L_WT + lane;                            // [s * 64]
   float* tr0 = sm + L_TR + wave * 640;
   float* tr1 = tr0 + 320;
   const int tr_w = n * 20 + 4 * g, tr_r = 80 * g + n;
-  const float* dpb = sm + L_DP + n * TB_PITCH + 40 * ty1 + 4 * tx1 + (g >> 1);   // + (2 ty2 + ty3 + a) * 10 + 2 tx2 + b
-  f4* red = reinterpret_cast<f4*>(sm + L_RED);
+  float* dpi = sm + L_DP + slot * 1664;
+  float* y1i = sm + L_Y1 + slot * (16 * TB_YP);
+  // dpred window of this lane's pixel, T form (B operand of the Toeplitz product): row (2 ty2 + a), column 2 tx2 + b' with b' = g
+  const float* dpT = dpi + n * TB_PITCH + 40 * ty1 + 4 * tx1 + g;
+  // P form (B operand of the output conv's weight gradient): pixel 4g + i, window element (a, b') = (n >> 2, n & 3)
+  const float* dpP = dpi + 4 * g * TB_PITCH + 40 * ty1 + 4 * tx1 + 10 * (n >> 2) + (n & 3);
+  f4* red = reinterpret_cast<f4*>(sm + L_RED) + slot * (4 * 4 * 64);
 
-  // weight-gradient accumulators, over all tiles of this workgroup
-  f4 dW2[2][4], dW3[4][2], dW4[2], aWc[9], db2[2], db3, db4;
+  // weight-gradient accumulators, over all tiles of this wave
+  f4 dW2[2][4], dW3[4][2], dW4[2], gT, db2[2], db3, db4;
   float dbc = 0.f;
   const f4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -124,17 +136,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
     for (int t = 0; t < 4; ++t) { dW2[c][t] = zero; dW3[t][c] = zero; }
   }
-#pragma unroll
-  for (int t = 0; t < 9; ++t) aWc[t] = zero;
-  db3 = zero; db4 = zero;
+  gT = zero; db3 = zero; db4 = zero;
 
-  for (int tile = (int)blockIdx.x; tile < ntiles; tile += (int)gridDim.x) {
+  for (int tp = (int)blockIdx.x; 2 * tp < ntiles; tp += (int)gridDim.x) {
+    const int tile = 2 * tp + slot;
+    const bool tile_on = tile < ntiles;   // wave-uniform
     const int P = 16 * tile + n;
     const bool px_ok = P < NP;
     const int Pc = px_ok ? P : NP - 1;
     // ---- stage the dpred windows of the tile's pixels (zero outside the image = the conv's SAME padding, and for the
-    // pixels past the end of the batch: everything they would add to a gradient is then zero) ----
-    for (int e = tid; e < 1600; e += 256) {
+    // pixels past the end of the batch: everything they would add to a gradient is then zero) and the activation tile ----
+    for (int e = stid; e < 1600; e += 256) {
       const int nn = e / 100, rc = e - nn * 100, r = rc / 10, c = rc - r * 10;
       const int PP = 16 * tile + nn;
       float v = 0.f;
@@ -143,144 +155,135 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         const int Y = 8 * y - 1 + r, X = 8 * x - 1 + c;
         if (Y >= 0 && Y < OH && X >= 0 && X < OW) v = p.dpred[((size_t)smp * OH + Y) * OW + X];
       }
-      sm[L_DP + nn * TB_PITCH + rc] = v;
+      dpi[nn * TB_PITCH + rc] = v;
+      if (r >= 1 && r <= 8 && c >= 1 && c <= 8) dbc += v;   // the interior of a window is the pixel's own block: every image pixel once
     }
-    // ---- the tile's input activation in both forms ----
-    f4 xs[4], y1p[4];
     {
-      const float* src = p.y1 + (size_t)Pc * 64 + 16 * g;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) xs[q] = *reinterpret_cast<const f4*>(src + 4 * q);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float* sp = p.y1 + (size_t)min(16 * tile + 4 * g + i, NP - 1) * 64 + n;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) y1p[t][i] = sp[16 * t];
-      }
+      const int nn = stid >> 4, c4 = (stid & 15) * 4;
+      const f4 v = *reinterpret_cast<const f4*>(p.y1 + (size_t)min(16 * tile + nn, NP - 1) * 64 + c4);
+      *reinterpret_cast<f4*>(y1i + nn * TB_YP + c4) = v;
     }
-    __syncthreads();   // A: windows staged (and the previous tile's reduction image read)
+    __syncthreads();   // A: images staged (and the previous tile's reduction image read)
 
-    // ================= this wave's tap of ConvT#2 =================
-    f4 z2[2] = {bz2[0], bz2[1]};
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const float xv = xs[s >> 2][s & 3];
-      z2[0] = mf(w1f[s * 64], xv, z2[0]);
-      z2[1] = mf(w1f[(16 + s) * 64], xv, z2[1]);
-    }
-    f4 y2[2], g2[2], y2p[2], dy2[2] = {zero, zero};
-    act(z2[0], y2[0], g2[0]); act(z2[1], y2[1], g2[1]);
-    y2p[0] = t2p(tr0, tr_w, tr_r, y2[0]);
-    y2p[1] = t2p(tr1, tr_w, tr_r, y2[1]);
-#pragma unroll
-    for (int tap2 = 0; tap2 < 4; ++tap2) {
-      const int ty2 = tap2 >> 1, tx2 = tap2 & 1;
-      // ---- forward: ConvT#3, ConvT#4 of this sub-tree ----
-      f4 z3 = bz3;
-#pragma unroll
-      for (int ks = 0; ks < 8; ++ks) z3 = mf(w2f[(tap2 * 8 + ks) * 64], ks < 4 ? y2[0][ks & 3] : y2[1][ks & 3], z3);
-      f4 y3, g3;
-      act(z3, y3, g3);
-      f4 z4[2] = {bz4, bz4}, y4[2], g4[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) z4[u] = mf(w3f[(u * 4 + i) * 64], y3[i], z4[u]);
-        act(z4[u], y4[u], g4[u]);
-      }
-      // ---- output conv: dY4[q][ci] = sum_{a,b} dpred[q + (a-1, b-1)] Wc[2-a][2-b][ci];  dWc[2-a][2-b][ci] += Y4[q][ci] dpred[q + (a-1, b-1)] ----
-      float dpw[4][3];
-#pragma unroll
-      for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 3; ++b) dpw[a][b] = dpb[(2 * ty2 + a) * 10 + 2 * tx2 + b];
-      f4 dz4[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        f4 dy4 = zero;
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-          for (int b = 0; b < 3; ++b) {
-            const float d = dpw[u + a][b];
-            const int t = (2 - a) * 3 + (2 - b);
-            dy4 = __builtin_elementwise_fma(wcr[t], f4{d, d, d, d}, dy4);
-            aWc[t] = __builtin_elementwise_fma(y4[u], f4{d, d, d, d}, aWc[t]);
-          }
-        dbc += dpw[u + 1][1];
-        dz4[u] = dy4 * g4[u];
-        db4 = db4 + dz4[u];
-      }
-      // ---- ConvT#4: data gradient, weight gradient ----
-      f4 dy3 = zero;
-#pragma unroll
-      for (int u = 0; u < 2; ++u)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dy3 = mf(a3b[(u * 4 + i) * 64], dz4[u][i], dy3);
-      const f4 dz3 = dy3 * g3;
-      db3 = db3 + dz3;
-      const f4 y3p = t2p(tr0, tr_w, tr_r, y3);
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const f4 dzp = t2p(tr1, tr_w, tr_r, dz4[u]);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) dW4[u] = mf(dzp[i], y3p[i], dW4[u]);
-      }
-      // ---- ConvT#3: weight gradient, data gradient ----
-      const f4 dz3p = t2p(tr0, tr_w, tr_r, dz3);
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          dW3[tap2][t] = mf(dz3p[i], y2p[t][i], dW3[tap2][t]);
-          dy2[t] = mf(a2b[((tap2 * 2 + t) * 4 + i) * 64], dz3[i], dy2[t]);
-        }
-    }
-    // ---- ConvT#2 (this wave's tap): weight gradient, data gradient ----
-    f4 dz2[2], dz2p[2];
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      dz2[c] = dy2[c] * g2[c];
-      db2[c] = db2[c] + dz2[c];
-    }
-    dz2p[0] = t2p(tr0, tr_w, tr_r, dz2[0]);
-    dz2p[1] = t2p(tr1, tr_w, tr_r, dz2[1]);
     f4 dy1[4] = {zero, zero, zero, zero};
+    if (tile_on) {
+      // ================= this wave's tap of ConvT#2 =================
+      f4 z2[2] = {bz2[0], bz2[1]};
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+      for (int q = 0; q < 4; ++q) {
+        const f4 xq = *reinterpret_cast<const f4*>(y1i + n * TB_YP + 16 * g + 4 * q);   // channel 16g + s, s = 4q + j
 #pragma unroll
-      for (int c = 0; c < 2; ++c)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          dW2[c][t] = mf(dz2p[c][i], y1p[t][i], dW2[c][t]);
-          dy1[t] = mf(a1b[((t * 2 + c) * 4 + i) * 64], dz2[c][i], dy1[t]);
+        for (int j = 0; j < 4; ++j) {
+          z2[0] = mf(w1f[(4 * q + j) * 64], xq[j], z2[0]);
+          z2[1] = mf(w1f[(16 + 4 * q + j) * 64], xq[j], z2[1]);
         }
+      }
+      f4 y2[2], g2[2], y2p[2], dy2[2] = {zero, zero};
+      act(z2[0], y2[0], g2[0]); act(z2[1], y2[1], g2[1]);
+      y2p[0] = t2p(tr0, tr_w, tr_r, y2[0]);
+      y2p[1] = t2p(tr1, tr_w, tr_r, y2[1]);
+#pragma unroll
+      for (int tap2 = 0; tap2 < 4; ++tap2) {
+        const int ty2 = tap2 >> 1, tx2 = tap2 & 1;
+        // ---- forward: ConvT#3, ConvT#4 of this sub-tree ----
+        f4 z3 = bz3;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) z3 = mf(w2f[(tap2 * 8 + ks) * 64], ks < 4 ? y2[0][ks & 3] : y2[1][ks & 3], z3);
+        f4 y3, g3;
+        act(z3, y3, g3);
+        f4 z4[2] = {bz4, bz4}, y4[2], g4[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) z4[u] = mf(w3f[(u * 4 + i) * 64], y3[i], z4[u]);
+          act(z4[u], y4[u], g4[u]);
+        }
+        // ---- output conv, banded (Toeplitz) over the 3 x 4 dpred window that serves both columns tx3 of a row pair:
+        //   dY4[(tx3, co)][px] = sum_{a, b'} Wt[(tx3, co)][(a, b')] dpred[row + a - 1][col0 + b' - 1],  Wt = Wc[2-a][2-(b'-tx3)][co] or 0
+        //   gT[(tx3, co)][(a, b')] += sum_px Y4[px][(tx3, co)] dpred[...]      (unfolded into dWc at the end) ----
+        float dpr[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) dpr[a] = dpT[(2 * ty2 + a) * 10 + 2 * tx2];
+        f4 dz4[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          f4 dy4 = zero;
+#pragma unroll
+          for (int s = 0; s < 3; ++s) dy4 = mf(wtp[s * 64], dpr[u + s], dy4);
+          dz4[u] = dy4 * g4[u];
+          db4 = db4 + dz4[u];
+          const f4 y4p = t2p(u ? tr1 : tr0, tr_w, tr_r, y4[u]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) gT = mf(y4p[i], dpP[i * TB_PITCH + (2 * ty2 + u) * 10 + 2 * tx2], gT);
+        }
+        // ---- ConvT#4: data gradient, weight gradient ----
+        f4 dy3 = zero;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dy3 = mf(a3b[(u * 4 + i) * 64], dz4[u][i], dy3);
+        const f4 dz3 = dy3 * g3;
+        db3 = db3 + dz3;
+        const f4 y3p = t2p(tr0, tr_w, tr_r, y3);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const f4 dzp = t2p(tr1, tr_w, tr_r, dz4[u]);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) dW4[u] = mf(dzp[i], y3p[i], dW4[u]);
+        }
+        // ---- ConvT#3: weight gradient, data gradient ----
+        const f4 dz3p = t2p(tr0, tr_w, tr_r, dz3);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            dW3[tap2][t] = mf(dz3p[i], y2p[t][i], dW3[tap2][t]);
+            dy2[t] = mf(a2b[((tap2 * 2 + t) * 4 + i) * 64], dz3[i], dy2[t]);
+          }
+      }
+      // ---- ConvT#2 (this wave's tap): weight gradient, data gradient ----
+      f4 dz2[2], dz2p[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        dz2[c] = dy2[c] * g2[c];
+        db2[c] = db2[c] + dz2[c];
+      }
+      dz2p[0] = t2p(tr0, tr_w, tr_r, dz2[0]);
+      dz2p[1] = t2p(tr1, tr_w, tr_r, dz2[1]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        f4 y1p;                                   // P form of channel tile t: pixel 4g + i, channel 16t + n
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y1p[i] = y1i[(4 * g + i) * TB_YP + 16 * t + n];
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            dW2[c][t] = mf(dz2p[c][i], y1p[i], dW2[c][t]);
+            dy1[t] = mf(a1b[((t * 2 + c) * 4 + i) * 64], dz2[c][i], dy1[t]);
+          }
+      }
+    }
     // ---- dY1 = sum over the four taps (waves, in wave order); wave w finishes channel tile w: x swish'(Z1), store ----
 #pragma unroll
-    for (int t = 0; t < 4; ++t) red[(wave * 4 + t) * 64 + lane] = dy1[t];
-    const f4 z1 = *reinterpret_cast<const f4*>(p.z1 + (size_t)Pc * 64 + 16 * wave + 4 * g);
+    for (int t = 0; t < 4; ++t) red[(tap1 * 4 + t) * 64 + lane] = dy1[t];
+    const f4 z1 = *reinterpret_cast<const f4*>(p.z1 + (size_t)Pc * 64 + 16 * tap1 + 4 * g);
     __syncthreads();   // B
     {
-      f4 s = red[(0 * 4 + wave) * 64 + lane];
+      f4 s = red[(0 * 4 + tap1) * 64 + lane];
 #pragma unroll
-      for (int w = 1; w < 4; ++w) s = s + red[(w * 4 + wave) * 64 + lane];
+      for (int w = 1; w < 4; ++w) s = s + red[(w * 4 + tap1) * 64 + lane];
       f4 yy, gd;
       act(z1, yy, gd);
-      if (px_ok) *reinterpret_cast<f4*>(p.dz1 + (size_t)P * 64 + 16 * wave + 4 * g) = s * gd;
+      if (px_ok) *reinterpret_cast<f4*>(p.dz1 + (size_t)P * 64 + 16 * tap1 + 4 * g) = s * gd;
     }
   }
 
   // ================= end: one slab of TT_PARAMS floats per workgroup, flat-parameter order =================
   float* slab = p.slabs + (size_t)blockIdx.x * TT_PARAMS;
-#pragma unroll
-  for (int c = 0; c < 2; ++c)
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) slab[TT_O_W1 + (wave * 32 + 16 * c + 4 * g + j) * 64 + 16 * t + n] = dW2[c][t][j];   // D[co 16c + 4g + j][ci 16t + n] of tap `wave`
   __syncthreads();   // the weight images are dead
   {
-    float* r40 = sm + E_R40 + wave * 40 * 64 + lane;
+    float* r40 = sm + E_R40 + wave * E_RW * 64 + lane;
 #pragma unroll
     for (int tap2 = 0; tap2 < 4; ++tap2)
 #pragma unroll
@@ -291,61 +294,90 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int j = 0; j < 4; ++j) r40[(32 + u * 4 + j) * 64] = dW4[u][j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r40[(40 + j) * 64] = gT[j];
     float* r2 = sm + E_R2 + wave * E_R2S;
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float v = red16(aWc[t][i]);
-        v += __shfl_xor(v, 32, 64);              // the two tx3 halves
-        if (n == 0 && g < 2) r2[t * 8 + 4 * h + i] = v;
-      }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       float v = red16(db4[i]);
-      v += __shfl_xor(v, 32, 64);
-      if (n == 0 && g < 2) r2[72 + 4 * h + i] = v;
+      v += __shfl_xor(v, 32, 64);              // the two tx3 halves
+      if (n == 0 && g < 2) r2[4 * h + i] = v;
       v = red16(db3[i]);
-      if (n == 0) r2[80 + 4 * g + i] = v;
+      if (n == 0) r2[8 + 4 * g + i] = v;
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         v = red16(db2[c][i]);
-        if (n == 0) r2[96 + 16 * c + 4 * g + i] = v;
+        if (n == 0) r2[24 + 16 * c + 4 * g + i] = v;
       }
     }
-    float v = red16(h == 0 ? dbc : 0.f);         // the two channel halves of a pixel sit in two lanes: count it once
+    float v = red16(dbc);
     v += __shfl_xor(v, 16, 64);
     v += __shfl_xor(v, 32, 64);
-    if (lane == 0) r2[128] = v;
+    if (lane == 0) r2[56] = v;
+  }
+  // ConvT#2's kernel: the two waves of tap w (slots 0 / 1) hold partial sums over different tiles: slot 1 parks its registers
+  // in the dead dY1 / transposition images, slot 0 adds and stores.  D[co 16c + 4g + j][ci 16t + n] of tap `tap1`.
+  float* park = sm + L_TR + tap1 * (32 * 64) + lane;   // 4 taps x 32 registers x 64 lanes = 8192 floats <= L_END - L_TR
+  if (slot == 1) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) park[((c * 4 + t) * 4 + j) * 64] = dW2[c][t][j];
   }
   __syncthreads();
+  if (slot == 0) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          slab[TT_O_W1 + (tap1 * 32 + 16 * c + 4 * g + j) * 64 + 16 * t + n] = dW2[c][t][j] + park[((c * 4 + t) * 4 + j) * 64];
+  }
   const float* R40 = sm + E_R40;
   const float* R2 = sm + E_R2;
-  for (int o = tid; o < 2048; o += 256) {        // ConvT#3 kernel (2, 2, 16, 32): flat (tap2*16 + co)*32 + ci
+  auto sum8 = [&](const float* base, int idx, int stride) {   // over the eight waves, fixed order
+    float v = base[idx];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) v += base[w * stride + idx];
+    return v;
+  };
+  for (int o = tid; o < 2048; o += 512) {        // ConvT#3 kernel (2, 2, 16, 32): flat (tap2*16 + co)*32 + ci
     const int tap2 = o >> 9, co = (o >> 5) & 15, ci = o & 31;
     const int idx = (((tap2 * 2 + (ci >> 4)) * 4 + (co & 3)) * 64) + 16 * (co >> 2) + (ci & 15);
-    slab[TT_O_W2 + o] = ((R40[idx] + R40[40 * 64 + idx]) + R40[2 * 40 * 64 + idx]) + R40[3 * 40 * 64 + idx];
+    slab[TT_O_W2 + o] = sum8(R40, idx, E_RW * 64);
   }
-  for (int o = tid; o < 512; o += 256) {         // ConvT#4 kernel (2, 2, 8, 16): flat (tap3*8 + co)*16 + ci; D row = 8 tx3 + co of tile u = ty3
+  {                                              // ConvT#4 kernel (2, 2, 8, 16): flat (tap3*8 + co)*16 + ci; D row = 8 tx3 + co of tile u = ty3
+    const int o = tid;
     const int tap3 = o >> 7, co = (o >> 4) & 7, ci = o & 15;
     const int row = 8 * (tap3 & 1) + co;
     const int idx = ((32 + (tap3 >> 1) * 4 + (row & 3)) * 64) + 16 * (row >> 2) + ci;
-    slab[TT_O_W3 + o] = ((R40[idx] + R40[40 * 64 + idx]) + R40[2 * 40 * 64 + idx]) + R40[3 * 40 * 64 + idx];
+    slab[TT_O_W3 + o] = sum8(R40, idx, E_RW * 64);
   }
-  if (tid < 129) {
-    const int o = tid;
-    const float v = ((R2[o] + R2[E_R2S + o]) + R2[2 * E_R2S + o]) + R2[3 * E_R2S + o];
-    if (o < 72) slab[TT_O_WC + o] = v;
-    else if (o < 80) slab[TT_O_B3 + o - 72] = v;
-    else if (o < 96) slab[TT_O_B2 + o - 80] = v;
-    else if (o < 128) slab[TT_O_B1 + o - 96] = v;
+  if (tid < 72) {                                // output conv (3, 3, 8): dWc[dy][dx][co] = sum_tx3 gT[(tx3, co)][(a, b') = (2 - dy, 2 - dx + tx3)]
+    const int dy = tid / 24, dx = (tid >> 3) % 3, co = tid & 7;
+    float v = 0.f;
+#pragma unroll
+    for (int tx3 = 0; tx3 < 2; ++tx3) {
+      const int row = 8 * tx3 + co, col = 4 * (2 - dy) + (2 - dx + tx3);
+      v += sum8(R40, (40 + (row & 3)) * 64 + 16 * (row >> 2) + col, E_RW * 64);
+    }
+    slab[TT_O_WC + tid] = v;
+  } else if (tid >= 128 && tid < 128 + 57) {
+    const int o = tid - 128;
+    const float v = sum8(R2, o, E_R2S);
+    if (o < 8) slab[TT_O_B3 + o] = v;
+    else if (o < 24) slab[TT_O_B2 + o - 8] = v;
+    else if (o < 56) slab[TT_O_B1 + o - 24] = v;
     else slab[TT_O_BC] = v;
   }
 }
 
 int tail_bwd32_blocks(int n, int H, int W, int num_cus) {
-  const int64_t tiles = ((int64_t)n * H * W + 15) / 16;
-  return (int)std::max<int64_t>(1, std::min<int64_t>(tiles, num_cus));
+  const int64_t pairs = (((int64_t)n * H * W + 15) / 16 + 1) / 2;   // a workgroup takes two tiles at a time
+  return (int)std::max<int64_t>(1, std::min<int64_t>(pairs, num_cus));
 }
 
 hipError_t launch_tail_bwd32(const TailBwdParams& p, int num_cus, hipStream_t s) {
@@ -358,7 +390,7 @@ hipError_t launch_tail_bwd32(const TailBwdParams& p, int num_cus, hipStream_t s)
   q.magic_w = (unsigned)(((1ull << 32) + p.W - 1) / p.W);
   hipError_t e = lds_attr_once(reinterpret_cast<const void*>(tail_bwd32), TB_LDS);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(tail_bwd32, dim3(tail_bwd32_blocks(p.n, p.H, p.W, num_cus)), dim3(256), TB_LDS, s, q);
+  hipLaunchKernelGGL(tail_bwd32, dim3(tail_bwd32_blocks(p.n, p.H, p.W, num_cus)), dim3(512), TB_LDS, s, q);
   return hipGetLastError();
 }
 
@@ -445,6 +477,13 @@ void train_tail_plan(const ModelDesc& desc, const int* desc_index, const size_t*
         const int r = 4 * (lane >> 4) + i;
         put(w3(2 * u + (r >> 3), r & 7, lane & 15), 1.0);
       }
+  align(); plan.wt = mp.size();
+  for (int s3 = 0; s3 < 3; ++s3)         // wt[s][lane] = Wc[2 - s][2 - (b' - tx3)][co] for 0 <= b' - tx3 <= 2, else 0; m = 8 tx3 + co, b' = kg
+    for (int lane = 0; lane < 64; ++lane) {
+      const int m = lane & 15, tx3 = m >> 3, co = m & 7, d = (lane >> 4) - tx3;
+      if (d >= 0 && d <= 2) put(WC + (size_t)((2 - s3) * 3 + (2 - d)) * 8 + co, 1.0);
+      else { mp.push_back(0); sc.push_back(0.f); }
+    }
   align(); plan.bias = mp.size();
   for (int c = 0; c < 32; ++c) put(B1 + c, 1.0);
   for (int c = 0; c < 16; ++c) put(B2 + c, 1.0);
@@ -452,7 +491,7 @@ void train_tail_plan(const ModelDesc& desc, const int* desc_index, const size_t*
   for (int k = 0; k < 72; ++k) put(WC + k, 1.0);
   put(BC, 1.0);
   align();
-  if (mp.size() - plan.wf < (size_t)TT_WF || plan.bias - plan.wb != (size_t)TT_WB) throw std::runtime_error("train_tail_plan: pack sizes");
+  if (mp.size() - plan.wf < (size_t)TT_WF || plan.wt - plan.wb != (size_t)TT_WB || plan.bias - plan.wt != (size_t)TT_WT) throw std::runtime_error("train_tail_plan: pack sizes");
   plan.ok = true;
 }
 
