@@ -100,6 +100,15 @@ __global__ void __launch_bounds__(256) gather_pack_f32(const float* __restrict__
   }
 }
 
+// x and y of a step into the staging buffers a captured step reads (one launch instead of two copies in front of every replay)
+__global__ void __launch_bounds__(256) stage_xy_f32(const float4* __restrict__ x, float4* __restrict__ xs, int64_t nx, const float4* __restrict__ y,
+                                                     float4* __restrict__ ys, int64_t ny) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nx + ny; i += (int64_t)gridDim.x * 256) {
+    if (i < ny) ys[i] = y[i];
+    else xs[i - ny] = x[i - ny];
+  }
+}
+
 // Keras Adam (sr-ae-conv.ipynb:c556 defaults): m,v moments, alpha_t = lr sqrt(1-b2^t)/(1-b1^t), p -= alpha_t m/(sqrt(v)+eps)
 __global__ void __launch_bounds__(256) adam_f32(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                  int64_t n, float alpha_t, float b1, float b2, float eps) {
@@ -476,6 +485,7 @@ struct Trainer {
   // endless recursion on ROCm 7.2, and with one-way dependencies the three-branch graph replayed level by level, 0.83 ms
   // against 0.72 for two branches.  The sums are ONE launch at the end of the aux stream instead: wgrad_finish_all_f32.)
   hipEvent_t ev_fin = nullptr;                     // end of the aux stream's work of the step
+  hipEvent_t ev_start = nullptr, ev_dpack = nullptr;   // the data-gradient operands are packed on the aux stream beside the forward pass
   bool overlap = true;                             // SRCFD_TRAIN_OVERLAP=0: everything on the caller's stream
   // A step is ~100 launches and event operations of 5-40 us kernels: issued one by one the host cannot keep the device
   // fed (20 % of the step was idle gaps).  The second time a step with the same buffers and batch size is asked for it is
@@ -511,6 +521,8 @@ Trainer::~Trainer() {
   if (cap_stream) (void)hipStreamDestroy(cap_stream);
   if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); }
   if (ev_fin) (void)hipEventDestroy(ev_fin);
+  if (ev_start) (void)hipEventDestroy(ev_start);
+  if (ev_dpack) (void)hipEventDestroy(ev_dpack);
   if (d_xs) (void)hipFree(d_xs);
   if (d_ys) (void)hipFree(d_ys);
   for (hipEvent_t e : ev_dz) (void)hipEventDestroy(e);
@@ -717,6 +729,8 @@ static int trainer_build(Trainer& t, const Model& model, int max_batch) {
   if (t.overlap) {
     HIPCHECK(hipStreamCreateWithFlags(&t.aux, hipStreamNonBlocking));
     HIPCHECK(hipEventCreateWithFlags(&t.ev_fin, hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&t.ev_start, hipEventDisableTiming));
+    HIPCHECK(hipEventCreateWithFlags(&t.ev_dpack, hipEventDisableTiming));
     for (size_t i = 0; i < t.layers.size(); ++i) {
       hipEvent_t a, b;
       HIPCHECK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
@@ -751,8 +765,16 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
   // 1. pack operands from the flat parameters
   hipLaunchKernelGGL(gather_pack_f32, grid(t.pack_elems), dim3(256), 0, s, params, t.d_pack_map, t.d_pack, (int64_t)t.pack_elems,
                      (const float*)t.d_pack_scale, (int64_t)(t.use_tail ? t.tail_pack_off : t.pack_elems));
-  if (t.dpack_elems) hipLaunchKernelGGL(gather_pack_f32, grid(t.dpack_elems), dim3(256), 0, s, params, t.d_dpack_map, t.d_dpack, (int64_t)t.dpack_elems,
-                                        (const float*)nullptr, (int64_t)t.dpack_elems);
+  // the data-gradient operands are not needed before the backward pass: packed on the aux stream, beside the forward pass
+  if (t.dpack_elems) {
+    if (t.overlap) {
+      HIPCHECK(hipEventRecord(t.ev_start, s));
+      HIPCHECK(hipStreamWaitEvent(t.aux, t.ev_start, 0));
+    }
+    hipLaunchKernelGGL(gather_pack_f32, grid(t.dpack_elems), dim3(256), 0, t.overlap ? t.aux : s, params, t.d_dpack_map, t.d_dpack,
+                       (int64_t)t.dpack_elems, (const float*)nullptr, (int64_t)t.dpack_elems);
+    if (t.overlap) HIPCHECK(hipEventRecord(t.ev_dpack, t.aux));
+  }
   // 2. forward, keeping Z (pre-activation) and Y (post) of every layer; with the fused tail the last four layers are one
   //    streaming launch that ends in the loss gradient (nothing of them is kept: tail_bwd32 recomputes what it needs)
   const int L = (int)t.layers.size();
@@ -813,6 +835,7 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
   for (auto& ft : ftab) ft.nops = 0;
   bool dz_done = false;  // the data-gradient GEMM below already multiplied by swish'(Z) of the layer it feeds (EpiAux mode 2)
   hipStream_t ws = t.overlap ? t.aux : s;
+  if (t.overlap && t.dpack_elems) HIPCHECK(hipStreamWaitEvent(s, t.ev_dpack, 0));
   if (t.use_tail) {      // every gradient of the last four layers + dZ of layer Lg - 1, from dpred (dbuf[1]) and that layer's Z / Y
     TailBwdParams q;
     q.y1 = t.Y[Lg - 1]; q.z1 = t.Z[Lg - 1]; q.dpred = t.dbuf[1]; q.dz1 = t.dbuf[0]; q.slabs = t.d_tail_slabs;
@@ -924,8 +947,16 @@ int srcfd_trainer_forward_backward(srcfd_trainer* t, const float* params_dev, co
   hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
   if (!tt.use_graph || n <= 0 || n > tt.max_batch) return srcfd::trainer_step(tt, params_dev, x_dev, y_dev, n, loss_scale, grads_dev, sse_dev, s);
   HIPCHECK(hipSetDevice(tt.device));
-  HIPCHECK(hipMemcpyAsync(tt.d_xs, x_dev, (size_t)n * tt.x_elems * sizeof(float), hipMemcpyDeviceToDevice, s));
-  HIPCHECK(hipMemcpyAsync(tt.d_ys, y_dev, (size_t)n * tt.y_elems * sizeof(float), hipMemcpyDeviceToDevice, s));
+  const size_t xe = (size_t)n * tt.x_elems, ye = (size_t)n * tt.y_elems;
+  if (((uintptr_t)x_dev | (uintptr_t)y_dev) % 16 == 0 && xe % 4 == 0 && ye % 4 == 0) {
+    const int64_t nx = (int64_t)(xe / 4), ny = (int64_t)(ye / 4);
+    hipLaunchKernelGGL(srcfd::stage_xy_f32, dim3((unsigned)std::min<int64_t>(2048, (nx + ny + 255) / 256)), dim3(256), 0, s,
+                       reinterpret_cast<const float4*>(x_dev), reinterpret_cast<float4*>(tt.d_xs), nx, reinterpret_cast<const float4*>(y_dev),
+                       reinterpret_cast<float4*>(tt.d_ys), ny);
+  } else {
+    HIPCHECK(hipMemcpyAsync(tt.d_xs, x_dev, xe * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHECK(hipMemcpyAsync(tt.d_ys, y_dev, ye * sizeof(float), hipMemcpyDeviceToDevice, s));
+  }
   Trainer::StepKey key;
   key.params = params_dev; key.grads = grads_dev; key.sse = sse_dev; key.n = n; key.loss_scale = loss_scale;
   Trainer::StepGraph* slot = nullptr;
