@@ -156,6 +156,8 @@ def test_bench_eight_rank_rehearsal():
     assert legs["headline_bf16"]["host_result"] == 768 * 160000 * 4 == b["host_pinned_bytes_rank0"]
     assert legs["parity_fp32"]["device_workspace"] == 2 * 768 * 160000 * 4        # ConvT#1's output is the largest tensor the f32 path materialises
     assert legs["tiled_f16"]["device_workspace"] == 2 * 6 * 160000 * 2 + 16 * 6 * 128 * 4
+    # rank 0's own legs run behind the collective ones for any N, the other ranks wait at one barrier: the N > 1 line carries them
+    assert r["cpu_baseline"]["value"] > 0 and r["cpu_baseline"]["kind"] == "port" and r["cpu_baseline"]["cores"] >= 1, r["cpu_baseline"]
     rc, recs, err = _run_bench(["--gpus", "8", "--steps", "3", "--warmup", "1"], {"SRCFD_BENCH_DRYRUN": "1", "SRCFD_BENCH_DRYRUN_FAIL_RANK": "5"})
     assert rc == 0 and recs[0]["leg_failed_somewhere"] is True
 
@@ -175,16 +177,43 @@ def test_bench_refuses_mismatched_world_and_diagnostic_switches():
     assert rc == 0 and len(recs) == 1
 
 
+def test_bench_refuses_a_stale_traffic_file(tmp_path, monkeypatch):
+    """roofline.traffic comes from committed PMC passes (bench.py cannot profile itself): a file is used only while the kernel
+    sources it was taken on are the ones in the tree."""
+    import json
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    name = "pmc_traffic_tail.json"
+    good = {"source": "x", "config": {"fields": 256, "precision": "bf16", "out_dtype": "f32"}, "hbm_bytes_per_launch": 123,
+            "kernel_source_stamp": bench.kernel_source_stamp(name)}
+    (tmp_path / "profiles").mkdir()
+    (tmp_path / "sr-for-cfd_amd").symlink_to(os.path.join(ROOT, "sr-for-cfd_amd"))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    (tmp_path / "profiles" / name).write_text(json.dumps(good))
+    assert bench.measured_traffic(256, "bf16", "f32") == (123, "x")
+    assert bench.measured_traffic(128, "bf16", "f32") == (None, None)                 # another configuration
+    (tmp_path / "profiles" / name).write_text(json.dumps(dict(good, kernel_source_stamp="0" * 16)))
+    t, why = bench.measured_traffic(256, "bf16", "f32")
+    assert t is None and "stale" in why
+    (tmp_path / "profiles" / name).write_text(json.dumps({k: v for k, v in good.items() if k != "kernel_source_stamp"}))
+    assert bench.measured_traffic(256, "bf16", "f32")[0] is None                      # an unstamped file counts as stale
+
+
 @pytest.mark.gpu
 def test_bench_two_ranks_share_one_gpu():
     """The full rank path of bench.py (`--gpus 2` -> two child ranks, barrier, MAX over ranks, aggregate) on ONE GPU with the
     gloo backend standing in for RCCL; 8 fields per rank.  n_gpus and the aggregate must reflect both ranks."""
-    rc, recs, err = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--fields", "8", "--no-cpu-baseline"],
-                               {"SRCFD_BENCH_BACKEND": "gloo"}, timeout=900)
+    rc, recs, err = _run_bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--fields", "16"],
+                               {"SRCFD_BENCH_BACKEND": "gloo", "SRCFD_BENCH_CPU_BUDGET_S": "1"}, timeout=900)
     assert rc == 0, err[-2000:]
     r = recs[0]
     assert r["n_gpus"] == 2 and r["world_size_reported"] == 2
-    assert r["value"] == pytest.approx(2 * 8 / (r["ms_per_step"] * 1e-3), rel=1e-3)
+    assert r["value"] == pytest.approx(2 * 16 / (r["ms_per_step"] * 1e-3), rel=1e-3)
+    # an N > 1 line is complete: CPU stand-in, both rooflines, the float64-oracle check of both paths, the host-buffer entry
+    assert r["cpu_baseline"]["value"] > 0 and r["cpu_baseline"]["gpu_rel_l2_vs_f64_oracle"]["bf16"] < 2e-2
+    assert r["parity_path"]["rel_l2_vs_f64_oracle"] <= 1e-5 and r["host_io"] is not None and "sub_record_errors" not in r, r.get("sub_record_errors")
+    assert r["kernels_ms_sum"] * r["kernels_ms_in_step_scale"] <= r["ms_per_step"] * 1.0001
     assert r["nonfinite"] == 0 and r["roofline"]["frac"] > 0
     assert r["parity_path"]["roofline"]["avg_launch_ms"] <= r["parity_path"]["ms_per_step"] * 1.02
     assert r["train"]["global_batch"] == 16 and r["train"]["loss_finite"]
