@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/srcfd.h"
+#include "abi_guard.h"
 
 namespace srcfd {
 void set_error(const std::string& m);
@@ -156,78 +157,80 @@ void under_relax(Grid& g, int k, double alpha) {  // bfs_ml_accelerated.py:371-3
 }  // namespace
 
 extern "C" int srcfd_coarse_solve(const srcfd_coarse_problem* pb, double* var_out, int* iterations, double rms_out[3]) {
-  using srcfd::set_error;
-  if (!pb || !var_out) { set_error("srcfd_coarse_solve: bad arguments"); return SRCFD_EINVAL; }
-  if (pb->nx < 3 || pb->ny < 3 || pb->nx > 4096 || pb->ny > 4096 || !(pb->lx > 0) || !(pb->ly > 0) || !(pb->reynolds > 0) || !(pb->rho > 0) ||
-      !(pb->dt > 0) || pb->max_iterations < 0 || (pb->scheme != SRCFD_SCHEME_QUICK && pb->scheme != SRCFD_SCHEME_UPWIND) ||
-      (pb->case_type != SRCFD_CASE_LDC && pb->case_type != SRCFD_CASE_BFS) || (pb->case_type == SRCFD_CASE_BFS && !(pb->channel_height > 0))) {
-    set_error("srcfd_coarse_solve: bad problem description");
-    return SRCFD_EINVAL;
-  }
-  Grid g;
-  g.nx = pb->nx; g.ny = pb->ny; g.sy = g.ny + 2; g.sx = (g.nx + 2) * (g.ny + 2);
-  g.dx = pb->lx / g.nx; g.dy = pb->ly / g.ny; g.volp = g.dx * g.dy;   // MeshParameters, :69-77
-  g.Var.assign((size_t)3 * g.sx, 0.0); g.Old.assign((size_t)3 * g.sx, 0.0); g.Ff.assign((size_t)4 * g.sx, 0.0);
-  const double nu = 1.0 / pb->reynolds;  // FluidProperties, :79-85
-  const bool quick = pb->scheme == SRCFD_SCHEME_QUICK;
-  const bool bfs = pb->case_type == SRCFD_CASE_BFS;
-  auto bc = [&](int k) {   // _apply_bc_wrapper (bfs_ml_accelerated.py:564-569); the cavity solver has no inlet override
-    apply_bc(g, k, pb->bc_type[k], pb->bc_value[k]);
-    if (bfs) apply_bfs_inlet(g, k, pb->step_height, pb->channel_height, pb->bulk_velocity);
-  };
-  // _initialize_fields, :377-390
-  for (int k = 0; k < 3; ++k) bc(k);
-  g.Old = g.Var;
-  linear_interpolation(g);
-  int count = 0;
-  bool converged = false;
-  double rms[3] = {0, 0, 0};
-  while (!converged && count < pb->max_iterations) {   // solve, :411-424
-    ++count;
-    // _implicit_solve, :433-470
-    // (BFS: each solve is followed by under-relaxation against the previous iterate, bfs_ml_accelerated.py:642-659)
-    for (int k = 0; k < 2; ++k) {
-      solve_momentum(g, quick, k, pb->dt, nu);
-      if (bfs) under_relax(g, k, pb->relax[k]);
-      bc(k);
+  return srcfd::abi_guard("srcfd_coarse_solve", [&]() -> int {
+    using srcfd::set_error;
+    if (!pb || !var_out) { set_error("srcfd_coarse_solve: bad arguments"); return SRCFD_EINVAL; }
+    if (pb->nx < 3 || pb->ny < 3 || pb->nx > 4096 || pb->ny > 4096 || !(pb->lx > 0) || !(pb->ly > 0) || !(pb->reynolds > 0) || !(pb->rho > 0) ||
+        !(pb->dt > 0) || pb->max_iterations < 0 || (pb->scheme != SRCFD_SCHEME_QUICK && pb->scheme != SRCFD_SCHEME_UPWIND) ||
+        (pb->case_type != SRCFD_CASE_LDC && pb->case_type != SRCFD_CASE_BFS) || (pb->case_type == SRCFD_CASE_BFS && !(pb->channel_height > 0))) {
+      set_error("srcfd_coarse_solve: bad problem description");
+      return SRCFD_EINVAL;
     }
+    Grid g;
+    g.nx = pb->nx; g.ny = pb->ny; g.sy = g.ny + 2; g.sx = (g.nx + 2) * (g.ny + 2);
+    g.dx = pb->lx / g.nx; g.dy = pb->ly / g.ny; g.volp = g.dx * g.dy;   // MeshParameters, :69-77
+    g.Var.assign((size_t)3 * g.sx, 0.0); g.Old.assign((size_t)3 * g.sx, 0.0); g.Ff.assign((size_t)4 * g.sx, 0.0);
+    const double nu = 1.0 / pb->reynolds;  // FluidProperties, :79-85
+    const bool quick = pb->scheme == SRCFD_SCHEME_QUICK;
+    const bool bfs = pb->case_type == SRCFD_CASE_BFS;
+    auto bc = [&](int k) {   // _apply_bc_wrapper (bfs_ml_accelerated.py:564-569); the cavity solver has no inlet override
+      apply_bc(g, k, pb->bc_type[k], pb->bc_value[k]);
+      if (bfs) apply_bfs_inlet(g, k, pb->step_height, pb->channel_height, pb->bulk_velocity);
+    };
+    // _initialize_fields, :377-390
+    for (int k = 0; k < 3; ++k) bc(k);
+    g.Old = g.Var;
     linear_interpolation(g);
-    solve_pressure(g, pb->dt, pb->rho);
-    if (bfs) under_relax(g, 2, pb->relax[2]);
-    bc(2);
-    double res[3] = {0, 0, 0};
-    for (int i = 1; i <= g.nx; ++i)       // correct_velocity, :323-335
-      for (int j = 1; j <= g.ny; ++j) {
-        g.v(0, i, j) = g.v(0, i, j) - pb->dt / pb->rho * (g.v(2, i + 1, j) - g.v(2, i - 1, j)) / (2 * g.dx);
-        g.v(1, i, j) = g.v(1, i, j) - pb->dt / pb->rho * (g.v(2, i, j + 1) - g.v(2, i, j - 1)) / (2 * g.dy);
-        for (int k = 0; k < 3; ++k) {
-          const double d = g.v(k, i, j) - g.Old[(size_t)k * g.sx + (size_t)i * g.sy + j];
-          res[k] += d * d;
+    int count = 0;
+    bool converged = false;
+    double rms[3] = {0, 0, 0};
+    while (!converged && count < pb->max_iterations) {   // solve, :411-424
+      ++count;
+      // _implicit_solve, :433-470
+      // (BFS: each solve is followed by under-relaxation against the previous iterate, bfs_ml_accelerated.py:642-659)
+      for (int k = 0; k < 2; ++k) {
+        solve_momentum(g, quick, k, pb->dt, nu);
+        if (bfs) under_relax(g, k, pb->relax[k]);
+        bc(k);
+      }
+      linear_interpolation(g);
+      solve_pressure(g, pb->dt, pb->rho);
+      if (bfs) under_relax(g, 2, pb->relax[2]);
+      bc(2);
+      double res[3] = {0, 0, 0};
+      for (int i = 1; i <= g.nx; ++i)       // correct_velocity, :323-335
+        for (int j = 1; j <= g.ny; ++j) {
+          g.v(0, i, j) = g.v(0, i, j) - pb->dt / pb->rho * (g.v(2, i + 1, j) - g.v(2, i - 1, j)) / (2 * g.dx);
+          g.v(1, i, j) = g.v(1, i, j) - pb->dt / pb->rho * (g.v(2, i, j + 1) - g.v(2, i, j - 1)) / (2 * g.dy);
+          for (int k = 0; k < 3; ++k) {
+            const double d = g.v(k, i, j) - g.Old[(size_t)k * g.sx + (size_t)i * g.sy + j];
+            res[k] += d * d;
+          }
         }
+      bc(0);
+      bc(1);
+      for (int i = 1; i <= g.nx; ++i)       // update_flux, :242-249
+        for (int j = 1; j <= g.ny; ++j) {
+          g.f(0, i, j) += -pb->dt / pb->rho * (g.v(2, i + 1, j) - g.v(2, i, j)) * g.dy / g.dx;
+          g.f(1, i, j) += -pb->dt / pb->rho * (g.v(2, i, j + 1) - g.v(2, i, j)) * g.dx / g.dy;
+          g.f(2, i, j) += -pb->dt / pb->rho * (g.v(2, i - 1, j) - g.v(2, i, j)) * g.dy / g.dx;
+          g.f(3, i, j) += -pb->dt / pb->rho * (g.v(2, i, j - 1) - g.v(2, i, j)) * g.dx / g.dy;
+        }
+      // _convergence_check, :472-505
+      converged = true;
+      for (int k = 0; k < 3; ++k) {
+        rms[k] = std::sqrt(res[k] / (g.nx * g.ny)) / pb->dt;
+        if (!std::isfinite(rms[k])) {
+          set_error("srcfd_coarse_solve: NaN or Inf in the residuals (solver instability)");   // the reference raises ValueError here
+          return SRCFD_EINVAL;
+        }
+        if (rms[k] > pb->tolerance[k]) converged = false;
       }
-    bc(0);
-    bc(1);
-    for (int i = 1; i <= g.nx; ++i)       // update_flux, :242-249
-      for (int j = 1; j <= g.ny; ++j) {
-        g.f(0, i, j) += -pb->dt / pb->rho * (g.v(2, i + 1, j) - g.v(2, i, j)) * g.dy / g.dx;
-        g.f(1, i, j) += -pb->dt / pb->rho * (g.v(2, i, j + 1) - g.v(2, i, j)) * g.dx / g.dy;
-        g.f(2, i, j) += -pb->dt / pb->rho * (g.v(2, i - 1, j) - g.v(2, i, j)) * g.dy / g.dx;
-        g.f(3, i, j) += -pb->dt / pb->rho * (g.v(2, i, j - 1) - g.v(2, i, j)) * g.dx / g.dy;
-      }
-    // _convergence_check, :472-505
-    converged = true;
-    for (int k = 0; k < 3; ++k) {
-      rms[k] = std::sqrt(res[k] / (g.nx * g.ny)) / pb->dt;
-      if (!std::isfinite(rms[k])) {
-        set_error("srcfd_coarse_solve: NaN or Inf in the residuals (solver instability)");   // the reference raises ValueError here
-        return SRCFD_EINVAL;
-      }
-      if (rms[k] > pb->tolerance[k]) converged = false;
+      if (!converged) g.Old = g.Var;
     }
-    if (!converged) g.Old = g.Var;
-  }
-  std::memcpy(var_out, g.Var.data(), g.Var.size() * sizeof(double));
-  if (iterations) *iterations = count;
-  if (rms_out) for (int k = 0; k < 3; ++k) rms_out[k] = rms[k];
-  return SRCFD_OK;
+    std::memcpy(var_out, g.Var.data(), g.Var.size() * sizeof(double));
+    if (iterations) *iterations = count;
+    if (rms_out) for (int k = 0; k < 3; ++k) rms_out[k] = rms[k];
+    return SRCFD_OK;
+  });
 }

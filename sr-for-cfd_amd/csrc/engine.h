@@ -3,9 +3,11 @@
 #include <hip/hip_runtime.h>
 
 #include <functional>
+#include <new>
 #include <string>
 #include <vector>
 
+#include "abi_guard.h"
 #include "kernels.h"
 #include "model.h"
 

@@ -733,19 +733,23 @@ const char* srcfd_last_error(void) { return srcfd::g_last_error.c_str(); }
 const char* srcfd_version(void) { return "srcfd 0.1 (gfx950)"; }
 
 int srcfd_device_count(void) {
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
-  return n;
+  return srcfd::abi_guard("srcfd_device_count", [&]() -> int {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+  });
 }
 
 int srcfd_host_alloc(size_t bytes, void** out) {
-  if (!out || bytes == 0) { set_error("srcfd_host_alloc: bad arguments"); return SRCFD_EINVAL; }
-  *out = nullptr;
-  int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess || n < 1) { (void)hipGetLastError(); set_error("no HIP device: page-locked memory needs the runtime"); return SRCFD_ENODEV; }
-  hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
-  if (e != hipSuccess) { (void)hipGetLastError(); *out = nullptr; set_error(std::string("hipHostMalloc failed: ") + hipGetErrorString(e)); return SRCFD_ENOMEM; }
-  return SRCFD_OK;
+  return srcfd::abi_guard("srcfd_host_alloc", [&]() -> int {
+    if (!out || bytes == 0) { set_error("srcfd_host_alloc: bad arguments"); return SRCFD_EINVAL; }
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n < 1) { (void)hipGetLastError(); set_error("no HIP device: page-locked memory needs the runtime"); return SRCFD_ENODEV; }
+    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { (void)hipGetLastError(); *out = nullptr; set_error(std::string("hipHostMalloc failed: ") + hipGetErrorString(e)); return SRCFD_ENOMEM; }
+    return SRCFD_OK;
+  });
 }
 
 void srcfd_host_free(void* p) {
@@ -753,148 +757,166 @@ void srcfd_host_free(void* p) {
 }
 
 int srcfd_model_load_h5(const char* encoder_h5, const char* decoder_h5, int device, srcfd_model** out) {
-  if (!out || (!encoder_h5 && !decoder_h5)) { set_error("srcfd_model_load_h5: bad arguments"); return SRCFD_EINVAL; }
-  *out = nullptr;
-  std::unique_ptr<Model> m(new Model());
-  m->device = device;
-  try {
-    if (encoder_h5) srcfd::append_h5_submodel(m->desc, encoder_h5);
-    if (decoder_h5) srcfd::append_h5_submodel(m->desc, decoder_h5);
-  } catch (const srcfd::FileError& e) {
-    set_error(e.msg);
-    return e.code;
-  } catch (const std::exception& e) {
-    set_error(e.what());
-    return SRCFD_EIO;
-  }
-  return srcfd::finish_create(m, out);
+  return srcfd::abi_guard("srcfd_model_load_h5", [&]() -> int {
+    if (!out || (!encoder_h5 && !decoder_h5)) { set_error("srcfd_model_load_h5: bad arguments"); return SRCFD_EINVAL; }
+    *out = nullptr;
+    std::unique_ptr<Model> m(new Model());
+    m->device = device;
+    try {
+      if (encoder_h5) srcfd::append_h5_submodel(m->desc, encoder_h5);
+      if (decoder_h5) srcfd::append_h5_submodel(m->desc, decoder_h5);
+    } catch (const srcfd::FileError& e) {
+      set_error(e.msg);
+      return e.code;
+    } catch (const std::exception& e) {
+      set_error(e.what());
+      return SRCFD_EIO;
+    }
+    return srcfd::finish_create(m, out);
+  });
 }
 
 int srcfd_model_load_superres_h5(const char* superres_h5, int device, srcfd_model** out) {
-  if (!out || !superres_h5) { set_error("srcfd_model_load_superres_h5: bad arguments"); return SRCFD_EINVAL; }
-  *out = nullptr;
-  std::unique_ptr<Model> m(new Model());
-  m->device = device;
-  try {
-    srcfd::append_h5_whole(m->desc, superres_h5);
-  } catch (const srcfd::FileError& e) {
-    set_error(e.msg);
-    return e.code;
-  } catch (const std::exception& e) {
-    set_error(e.what());
-    return SRCFD_EIO;
-  }
-  return srcfd::finish_create(m, out);
+  return srcfd::abi_guard("srcfd_model_load_superres_h5", [&]() -> int {
+    if (!out || !superres_h5) { set_error("srcfd_model_load_superres_h5: bad arguments"); return SRCFD_EINVAL; }
+    *out = nullptr;
+    std::unique_ptr<Model> m(new Model());
+    m->device = device;
+    try {
+      srcfd::append_h5_whole(m->desc, superres_h5);
+    } catch (const srcfd::FileError& e) {
+      set_error(e.msg);
+      return e.code;
+    } catch (const std::exception& e) {
+      set_error(e.what());
+      return SRCFD_EIO;
+    }
+    return srcfd::finish_create(m, out);
+  });
 }
 
 int srcfd_model_save_superres_h5(const srcfd_model* m, const char* superres_h5) {
-  if (!m || !superres_h5) { set_error("srcfd_model_save_superres_h5: bad arguments"); return SRCFD_EINVAL; }
-  try {
-    srcfd::save_h5_whole(M(m)->desc, superres_h5);
-  } catch (const srcfd::FileError& e) {
-    set_error(e.msg);
-    return e.code;
-  }
-  return SRCFD_OK;
+  return srcfd::abi_guard("srcfd_model_save_superres_h5", [&]() -> int {
+    if (!m || !superres_h5) { set_error("srcfd_model_save_superres_h5: bad arguments"); return SRCFD_EINVAL; }
+    try {
+      srcfd::save_h5_whole(M(m)->desc, superres_h5);
+    } catch (const srcfd::FileError& e) {
+      set_error(e.msg);
+      return e.code;
+    }
+    return SRCFD_OK;
+  });
 }
 
 int srcfd_model_create(const srcfd_layer* layers, int n_layers, const int in_shape[3], int device, srcfd_model** out) {
-  if (!out || !layers || n_layers <= 0 || !in_shape) { set_error("srcfd_model_create: bad arguments"); return SRCFD_EINVAL; }
-  *out = nullptr;
-  std::unique_ptr<Model> m(new Model());
-  m->device = device;
-  for (int i = 0; i < 3; ++i) m->desc.in_shape[i] = in_shape[i];
-  int cur[3] = {in_shape[0], in_shape[1], in_shape[2]};
-  (void)cur;
-  for (int i = 0; i < n_layers; ++i) {
-    const srcfd_layer& s = layers[i];
-    srcfd::Layer L;
-    L.kind = s.kind; L.act = s.activation; L.kh = s.kh; L.kw = s.kw; L.stride = s.stride > 0 ? s.stride : 1; L.same = s.same_padding;
-    L.cin = s.cin; L.cout = s.cout;
-    for (int k = 0; k < 3; ++k) L.reshape[k] = s.reshape[k];
-    L.name = (s.name && *s.name) ? std::string(s.name) : "layer_" + std::to_string(i);
-    if (s.kind == SRCFD_LAYER_CONV2D || s.kind == SRCFD_LAYER_CONV2D_TRANSPOSE || s.kind == SRCFD_LAYER_DENSE) {
-      if (!s.kernel || s.cin <= 0 || s.cout <= 0) { set_error("layer " + std::to_string(i) + ": missing kernel / channels"); return SRCFD_EINVAL; }
-      if (s.kind == SRCFD_LAYER_DENSE) { L.kh = L.kw = 1; }
-      if (L.kh <= 0 || L.kw <= 0) { set_error("layer " + std::to_string(i) + ": bad kernel size"); return SRCFD_EINVAL; }
-      size_t cnt = (size_t)L.kh * L.kw * s.cin * s.cout;
-      L.kernel.assign(s.kernel, s.kernel + cnt);
-      if (s.bias) L.bias.assign(s.bias, s.bias + s.cout);
-      else L.bias.assign(s.cout, 0.f);
+  return srcfd::abi_guard("srcfd_model_create", [&]() -> int {
+    if (!out || !layers || n_layers <= 0 || !in_shape) { set_error("srcfd_model_create: bad arguments"); return SRCFD_EINVAL; }
+    *out = nullptr;
+    std::unique_ptr<Model> m(new Model());
+    m->device = device;
+    for (int i = 0; i < 3; ++i) m->desc.in_shape[i] = in_shape[i];
+    int cur[3] = {in_shape[0], in_shape[1], in_shape[2]};
+    (void)cur;
+    for (int i = 0; i < n_layers; ++i) {
+      const srcfd_layer& s = layers[i];
+      srcfd::Layer L;
+      L.kind = s.kind; L.act = s.activation; L.kh = s.kh; L.kw = s.kw; L.stride = s.stride > 0 ? s.stride : 1; L.same = s.same_padding;
+      L.cin = s.cin; L.cout = s.cout;
+      for (int k = 0; k < 3; ++k) L.reshape[k] = s.reshape[k];
+      L.name = (s.name && *s.name) ? std::string(s.name) : "layer_" + std::to_string(i);
+      if (s.kind == SRCFD_LAYER_CONV2D || s.kind == SRCFD_LAYER_CONV2D_TRANSPOSE || s.kind == SRCFD_LAYER_DENSE) {
+        if (!s.kernel || s.cin <= 0 || s.cout <= 0) { set_error("layer " + std::to_string(i) + ": missing kernel / channels"); return SRCFD_EINVAL; }
+        if (s.kind == SRCFD_LAYER_DENSE) { L.kh = L.kw = 1; }
+        if (L.kh <= 0 || L.kw <= 0) { set_error("layer " + std::to_string(i) + ": bad kernel size"); return SRCFD_EINVAL; }
+        size_t cnt = (size_t)L.kh * L.kw * s.cin * s.cout;
+        L.kernel.assign(s.kernel, s.kernel + cnt);
+        if (s.bias) L.bias.assign(s.bias, s.bias + s.cout);
+        else L.bias.assign(s.cout, 0.f);
+      }
+      m->desc.layers.push_back(std::move(L));
     }
-    m->desc.layers.push_back(std::move(L));
-  }
-  // A graph with a `latent_vector` layer in the middle is the encoder/decoder pair of SuperResolutionAE
-  // (sr-ae-conv.ipynb:c162-169, c277-287): keep the two halves as separate sub-models so that save_h5 writes the
-  // `vanilla_encoder...h5` / `vanilla_decoder...h5` pair the solvers load (PyCFD_ML_accelerated.py:831-832).
-  int cut = -1;
-  for (int i = 0; i + 1 < n_layers; ++i)
-    if (m->desc.layers[i].name == "latent_vector") cut = i + 1;
-  if (cut > 0) {
-    try { m->desc.infer_shapes(); } catch (const std::exception& e) { set_error(e.what()); return SRCFD_EINVAL; }
-    srcfd::SubModel enc, dec;
-    enc.name = "encoder_" + std::to_string(in_shape[0]); enc.input_name = enc.name + "_input"; enc.first = 0; enc.count = cut;
-    dec.name = "decoder_" + std::to_string(m->desc.out_shape()[0]); dec.input_name = dec.name + "_input"; dec.first = cut; dec.count = n_layers - cut;
-    m->desc.subs.push_back(enc);
-    m->desc.subs.push_back(dec);
-  } else {
-    srcfd::SubModel sub;
-    sub.name = "model"; sub.input_name = "model_input"; sub.first = 0; sub.count = n_layers;
-    m->desc.subs.push_back(sub);
-  }
-  return srcfd::finish_create(m, out);
+    // A graph with a `latent_vector` layer in the middle is the encoder/decoder pair of SuperResolutionAE
+    // (sr-ae-conv.ipynb:c162-169, c277-287): keep the two halves as separate sub-models so that save_h5 writes the
+    // `vanilla_encoder...h5` / `vanilla_decoder...h5` pair the solvers load (PyCFD_ML_accelerated.py:831-832).
+    int cut = -1;
+    for (int i = 0; i + 1 < n_layers; ++i)
+      if (m->desc.layers[i].name == "latent_vector") cut = i + 1;
+    if (cut > 0) {
+      try { m->desc.infer_shapes(); } catch (const std::exception& e) { set_error(e.what()); return SRCFD_EINVAL; }
+      srcfd::SubModel enc, dec;
+      enc.name = "encoder_" + std::to_string(in_shape[0]); enc.input_name = enc.name + "_input"; enc.first = 0; enc.count = cut;
+      dec.name = "decoder_" + std::to_string(m->desc.out_shape()[0]); dec.input_name = dec.name + "_input"; dec.first = cut; dec.count = n_layers - cut;
+      m->desc.subs.push_back(enc);
+      m->desc.subs.push_back(dec);
+    } else {
+      srcfd::SubModel sub;
+      sub.name = "model"; sub.input_name = "model_input"; sub.first = 0; sub.count = n_layers;
+      m->desc.subs.push_back(sub);
+    }
+    return srcfd::finish_create(m, out);
+  });
 }
 
 void srcfd_model_destroy(srcfd_model* m) { delete M(m); }
 
 int srcfd_model_input_shape(const srcfd_model* m, int shape[3]) {
-  if (!m || !shape) { set_error("bad arguments"); return SRCFD_EINVAL; }
-  for (int i = 0; i < 3; ++i) shape[i] = M(m)->desc.in_shape[i];
-  return SRCFD_OK;
+  return srcfd::abi_guard("srcfd_model_input_shape", [&]() -> int {
+    if (!m || !shape) { set_error("bad arguments"); return SRCFD_EINVAL; }
+    for (int i = 0; i < 3; ++i) shape[i] = M(m)->desc.in_shape[i];
+    return SRCFD_OK;
+  });
 }
 int srcfd_model_output_shape(const srcfd_model* m, int shape[3]) {
-  if (!m || !shape) { set_error("bad arguments"); return SRCFD_EINVAL; }
-  for (int i = 0; i < 3; ++i) shape[i] = M(m)->desc.out_shape()[i];
-  return SRCFD_OK;
+  return srcfd::abi_guard("srcfd_model_output_shape", [&]() -> int {
+    if (!m || !shape) { set_error("bad arguments"); return SRCFD_EINVAL; }
+    for (int i = 0; i < 3; ++i) shape[i] = M(m)->desc.out_shape()[i];
+    return SRCFD_OK;
+  });
 }
 int srcfd_model_num_layers(const srcfd_model* m) { return m ? (int)M(m)->desc.layers.size() : SRCFD_EINVAL; }
 
 int srcfd_model_get_layer(const srcfd_model* m, int i, srcfd_layer* layer, char* name, size_t name_len) {
-  if (!m || !layer || i < 0 || i >= (int)M(m)->desc.layers.size()) { set_error("bad arguments"); return SRCFD_EINVAL; }
-  const srcfd::Layer& L = M(m)->desc.layers[i];
-  layer->kind = L.kind; layer->activation = L.act; layer->kh = L.kh; layer->kw = L.kw; layer->stride = L.stride;
-  layer->same_padding = L.same; layer->cin = L.cin; layer->cout = L.cout;
-  for (int k = 0; k < 3; ++k) layer->reshape[k] = L.reshape[k];
-  layer->kernel = L.kernel.empty() ? nullptr : L.kernel.data();
-  layer->bias = L.bias.empty() ? nullptr : L.bias.data();
-  layer->name = L.name.c_str();
-  if (name && name_len) { std::snprintf(name, name_len, "%s", L.name.c_str()); }
-  return SRCFD_OK;
+  return srcfd::abi_guard("srcfd_model_get_layer", [&]() -> int {
+    if (!m || !layer || i < 0 || i >= (int)M(m)->desc.layers.size()) { set_error("bad arguments"); return SRCFD_EINVAL; }
+    const srcfd::Layer& L = M(m)->desc.layers[i];
+    layer->kind = L.kind; layer->activation = L.act; layer->kh = L.kh; layer->kw = L.kw; layer->stride = L.stride;
+    layer->same_padding = L.same; layer->cin = L.cin; layer->cout = L.cout;
+    for (int k = 0; k < 3; ++k) layer->reshape[k] = L.reshape[k];
+    layer->kernel = L.kernel.empty() ? nullptr : L.kernel.data();
+    layer->bias = L.bias.empty() ? nullptr : L.bias.data();
+    layer->name = L.name.c_str();
+    if (name && name_len) { std::snprintf(name, name_len, "%s", L.name.c_str()); }
+    return SRCFD_OK;
+  });
 }
 
 int64_t srcfd_model_macs_per_sample(const srcfd_model* m) { return m ? M(m)->desc.macs_per_sample() : 0; }
 
 int srcfd_model_set_precision(srcfd_model* m, int precision) {
-  if (!m || precision < 0 || precision > SRCFD_PREC_F16) { set_error("bad precision"); return SRCFD_EINVAL; }
-  if ((precision == SRCFD_PREC_BF16 || precision == SRCFD_PREC_F16) && !M(m)->has_fused) {
-    set_error("bf16/f16 precision needs the encoder_10+decoder_400 layer graph");
-    return SRCFD_EINVAL;
-  }
-  M(m)->precision = precision;
-  M(m)->drop_graph();
-  return SRCFD_OK;
+  return srcfd::abi_guard("srcfd_model_set_precision", [&]() -> int {
+    if (!m || precision < 0 || precision > SRCFD_PREC_F16) { set_error("bad precision"); return SRCFD_EINVAL; }
+    if ((precision == SRCFD_PREC_BF16 || precision == SRCFD_PREC_F16) && !M(m)->has_fused) {
+      set_error("bf16/f16 precision needs the encoder_10+decoder_400 layer graph");
+      return SRCFD_EINVAL;
+    }
+    M(m)->precision = precision;
+    M(m)->drop_graph();
+    return SRCFD_OK;
+  });
 }
 int srcfd_model_reserve(srcfd_model* m, int n) {
-  if (!m || n < 0) { set_error("bad arguments"); return SRCFD_EINVAL; }
-  srcfd::Model& mm = *M(m);
-  if (mm.device < 0) { set_error("host-only handle: no device was requested at create"); return SRCFD_ENODEV; }
-  if (n == 0) return SRCFD_OK;
-  HIPCHECK(hipSetDevice(mm.device));
-  if (mm.precision == SRCFD_PREC_BF16 || mm.precision == SRCFD_PREC_F16) {
-    if (!mm.has_fused) { set_error("bf16/f16 precision needs the encoder_10+decoder_400 layer graph; use SRCFD_PREC_FP32 for other graphs"); return SRCFD_EINVAL; }
-    return srcfd::fused_reserve(mm, n);
-  }
-  return mm.ensure_workspace(n);
+  return srcfd::abi_guard("srcfd_model_reserve", [&]() -> int {
+    if (!m || n < 0) { set_error("bad arguments"); return SRCFD_EINVAL; }
+    srcfd::Model& mm = *M(m);
+    if (mm.device < 0) { set_error("host-only handle: no device was requested at create"); return SRCFD_ENODEV; }
+    if (n == 0) return SRCFD_OK;
+    HIPCHECK(hipSetDevice(mm.device));
+    if (mm.precision == SRCFD_PREC_BF16 || mm.precision == SRCFD_PREC_F16) {
+      if (!mm.has_fused) { set_error("bf16/f16 precision needs the encoder_10+decoder_400 layer graph; use SRCFD_PREC_FP32 for other graphs"); return SRCFD_EINVAL; }
+      return srcfd::fused_reserve(mm, n);
+    }
+    return mm.ensure_workspace(n);
+  });
 }
 
 int srcfd_model_get_precision(const srcfd_model* m) { return m ? M(m)->precision : SRCFD_EINVAL; }
@@ -902,116 +924,134 @@ int srcfd_model_has_fused_path(const srcfd_model* m) { return m ? (int)M(m)->has
 
 int srcfd_predict(srcfd_model* m, const float* x, int n, const float* in_affine, const float* out_affine, float* y, int flags,
                   int64_t* n_nonfinite) {
-  if (!m) { set_error("null model"); return SRCFD_EINVAL; }
-  return M(m)->predict_host(x, n, in_affine, out_affine, y, flags, n_nonfinite);
+  return srcfd::abi_guard("srcfd_predict", [&]() -> int {
+    if (!m) { set_error("null model"); return SRCFD_EINVAL; }
+    return M(m)->predict_host(x, n, in_affine, out_affine, y, flags, n_nonfinite);
+  });
 }
 
 int srcfd_predict_device(srcfd_model* m, const void* x_dev, int n, const float* in_affine_dev, const float* out_affine_dev,
                          void* y_dev, int out_dtype, int flags, int64_t* nonfinite_dev, void* hip_stream) {
-  if (!m || (n > 0 && (!x_dev || !y_dev))) { set_error("bad arguments"); return SRCFD_EINVAL; }
-  return M(m)->predict_device(x_dev, n, in_affine_dev, out_affine_dev, y_dev, out_dtype, flags,
-                              reinterpret_cast<unsigned long long*>(nonfinite_dev), reinterpret_cast<hipStream_t>(hip_stream));
+  return srcfd::abi_guard("srcfd_predict_device", [&]() -> int {
+    if (!m || (n > 0 && (!x_dev || !y_dev))) { set_error("bad arguments"); return SRCFD_EINVAL; }
+    return M(m)->predict_device(x_dev, n, in_affine_dev, out_affine_dev, y_dev, out_dtype, flags,
+                                reinterpret_cast<unsigned long long*>(nonfinite_dev), reinterpret_cast<hipStream_t>(hip_stream));
+  });
 }
 
 int srcfd_model_workspace(srcfd_model* m, int n, size_t* bytes) {
-  if (!m) { set_error("null model"); return SRCFD_EINVAL; }
-  int chunk = std::min(std::max(n, 1), M(m)->chunk_cap());
-  if (bytes) *bytes = 2 * (size_t)chunk * M(m)->max_act_elems() * sizeof(float);
-  return chunk;
+  return srcfd::abi_guard("srcfd_model_workspace", [&]() -> int {
+    if (!m) { set_error("null model"); return SRCFD_EINVAL; }
+    int chunk = std::min(std::max(n, 1), M(m)->chunk_cap());
+    if (bytes) *bytes = 2 * (size_t)chunk * M(m)->max_act_elems() * sizeof(float);
+    return chunk;
+  });
 }
 
 int srcfd_model_footprint(const srcfd_model* m, int n, int precision, size_t bytes[4]) {
-  if (!m || !bytes || n < 0 || precision < 0 || precision > SRCFD_PREC_F16) { set_error("bad arguments"); return SRCFD_EINVAL; }
-  const srcfd::Model& mm = *M(m);
-  const bool lowp = precision == SRCFD_PREC_BF16 || precision == SRCFD_PREC_F16;
-  if (lowp && !mm.has_fused) { set_error("bf16/f16 precision needs the encoder_10+decoder_400 layer graph"); return SRCFD_EINVAL; }
-  int shp_in[3] = {0, 0, 0}, shp_out[3] = {0, 0, 0};
-  (void)srcfd_model_input_shape(m, shp_in);
-  (void)srcfd_model_output_shape(m, shp_out);
-  const size_t in_elems = (size_t)shp_in[0] * shp_in[1] * shp_in[2], out_elems = (size_t)shp_out[0] * shp_out[1] * shp_out[2];
-  size_t params = 0;
-  for (const auto& L : mm.desc.layers) params += L.kernel.size() + L.bias.size();
-  if (lowp) {
-    const size_t want = (size_t)std::min(n, 1024);
-    bytes[0] = want ? 2 * want * 160000 * sizeof(uint16_t) + 16 * want * 128 * sizeof(float) : 0;   // fused_reserve: two activation buffers + the dense split-K slabs
-    bytes[1] = params * (sizeof(float) + 2 * sizeof(uint16_t));   // f32 weights + the 16-bit GEMM layout + fragment re-orderings (upper bound: every layer twice)
-  } else {
-    const int chunk = n ? std::min(n, mm.chunk_cap()) : 0;
-    bytes[0] = 2 * (size_t)chunk * mm.max_act_elems() * sizeof(float);
-    bytes[1] = params * sizeof(float) * 2;   // packed weights + the per-layer operand orders of the fused f32 kernels (upper bound)
-  }
-  const size_t stage = (size_t)std::min(n, 256);
-  bytes[2] = stage * (in_elems + 2 * out_elems + 4) * sizeof(float);   // predict_host: input, two result buffers, affine pairs
-  bytes[3] = (size_t)n * out_elems * sizeof(float);                    // what ONE host result of the call takes (pool buffer or caller's array)
-  return SRCFD_OK;
+  return srcfd::abi_guard("srcfd_model_footprint", [&]() -> int {
+    if (!m || !bytes || n < 0 || precision < 0 || precision > SRCFD_PREC_F16) { set_error("bad arguments"); return SRCFD_EINVAL; }
+    const srcfd::Model& mm = *M(m);
+    const bool lowp = precision == SRCFD_PREC_BF16 || precision == SRCFD_PREC_F16;
+    if (lowp && !mm.has_fused) { set_error("bf16/f16 precision needs the encoder_10+decoder_400 layer graph"); return SRCFD_EINVAL; }
+    int shp_in[3] = {0, 0, 0}, shp_out[3] = {0, 0, 0};
+    (void)srcfd_model_input_shape(m, shp_in);
+    (void)srcfd_model_output_shape(m, shp_out);
+    const size_t in_elems = (size_t)shp_in[0] * shp_in[1] * shp_in[2], out_elems = (size_t)shp_out[0] * shp_out[1] * shp_out[2];
+    size_t params = 0;
+    for (const auto& L : mm.desc.layers) params += L.kernel.size() + L.bias.size();
+    if (lowp) {
+      const size_t want = (size_t)std::min(n, 1024);
+      bytes[0] = want ? 2 * want * 160000 * sizeof(uint16_t) + 16 * want * 128 * sizeof(float) : 0;   // fused_reserve: two activation buffers + the dense split-K slabs
+      bytes[1] = params * (sizeof(float) + 2 * sizeof(uint16_t));   // f32 weights + the 16-bit GEMM layout + fragment re-orderings (upper bound: every layer twice)
+    } else {
+      const int chunk = n ? std::min(n, mm.chunk_cap()) : 0;
+      bytes[0] = 2 * (size_t)chunk * mm.max_act_elems() * sizeof(float);
+      bytes[1] = params * sizeof(float) * 2;   // packed weights + the per-layer operand orders of the fused f32 kernels (upper bound)
+    }
+    const size_t stage = (size_t)std::min(n, 256);
+    bytes[2] = stage * (in_elems + 2 * out_elems + 4) * sizeof(float);   // predict_host: input, two result buffers, affine pairs
+    bytes[3] = (size_t)n * out_elems * sizeof(float);                    // what ONE host result of the call takes (pool buffer or caller's array)
+    return SRCFD_OK;
+  });
 }
 
 int srcfd_model_set_profiling(srcfd_model* m, int enable) {
-  if (!m) { set_error("null model"); return SRCFD_EINVAL; }
-  M(m)->profiling = enable != 0;
-  M(m)->prof_used = 0;
-  return SRCFD_OK;
+  return srcfd::abi_guard("srcfd_model_set_profiling", [&]() -> int {
+    if (!m) { set_error("null model"); return SRCFD_EINVAL; }
+    M(m)->profiling = enable != 0;
+    M(m)->prof_used = 0;
+    return SRCFD_OK;
+  });
 }
 
 int srcfd_model_get_profile(srcfd_model* m, char* names, size_t names_len, float* ms, int* count, int max_count) {
-  if (!m || !count) { set_error("bad arguments"); return SRCFD_EINVAL; }
-  Model* mm = M(m);
-  if (mm->device < 0) { set_error("host-only handle"); return SRCFD_ENODEV; }
-  HIPCHECK(hipSetDevice(mm->device));
-  HIPCHECK(hipDeviceSynchronize());
-  std::string joined;
-  int n = 0;
-  for (size_t i = 0; i < mm->prof_used && n < max_count; ++i, ++n) {
-    float t = 0.f;
-    HIPCHECK(hipEventElapsedTime(&t, mm->prof_events[i].a, mm->prof_events[i].b));
-    if (ms) ms[n] = t;
-    if (n) joined += '\n';
-    joined += mm->prof_events[i].name;
-  }
-  *count = n;
-  if (names && names_len) std::snprintf(names, names_len, "%s", joined.c_str());
-  return SRCFD_OK;
+  return srcfd::abi_guard("srcfd_model_get_profile", [&]() -> int {
+    if (!m || !count) { set_error("bad arguments"); return SRCFD_EINVAL; }
+    Model* mm = M(m);
+    if (mm->device < 0) { set_error("host-only handle"); return SRCFD_ENODEV; }
+    HIPCHECK(hipSetDevice(mm->device));
+    HIPCHECK(hipDeviceSynchronize());
+    std::string joined;
+    int n = 0;
+    for (size_t i = 0; i < mm->prof_used && n < max_count; ++i, ++n) {
+      float t = 0.f;
+      HIPCHECK(hipEventElapsedTime(&t, mm->prof_events[i].a, mm->prof_events[i].b));
+      if (ms) ms[n] = t;
+      if (n) joined += '\n';
+      joined += mm->prof_events[i].name;
+    }
+    *count = n;
+    if (names && names_len) std::snprintf(names, names_len, "%s", joined.c_str());
+    return SRCFD_OK;
+  });
 }
 
 int srcfd_model_last_plan(const srcfd_model* m, char* buf, size_t buf_len) {
-  if (!m || !buf || buf_len == 0) { set_error("bad arguments"); return SRCFD_EINVAL; }
-  const srcfd::Plan& p = M(m)->plan;
-  const char* prec = p.precision == SRCFD_PREC_BF16 ? "bf16" : p.precision == SRCFD_PREC_F16 ? "f16" : p.precision == SRCFD_PREC_FP32 ? "fp32" : "fp32_naive";
-  char tmp[256];
-  if (p.fused)
-    snprintf(tmp, sizeof(tmp), "precision=%s encoder=%s dense_1=%s middle=%s tail=%s tail_seg=%d graph=%s", prec, p.sw.enc16 ? "enc16" : "layers",
-             p.sw.dense1_16 ? "dense1_16" : "gemm16", p.sw.mid16 ? (p.sw.mid_waves == 4 ? "mid16_4x32" : p.sw.mid_waves == 16 ? "mid16_16x32" : p.sw.mid_shape == 1 ? "mid16_8x32" : p.sw.mid_shape == 2 ? "mid16_8x64" : "mid16_4x64") : "gemm16", p.sw.tail16s ? "tail16s" : "tail16", p.tail_seg,
-             p.graph == 2 ? "replay" : p.graph == 1 ? "capture" : "eager");
-  else
-    snprintf(tmp, sizeof(tmp), "precision=%s encoder=%s dense_1=%s graph=%s", prec, p.sw.enc32 ? "enc32" : "layers",
-             p.sw.skinny32 ? "dense_skinny32" : "gemm32", p.graph == 2 ? "replay" : p.graph == 1 ? "capture" : "eager");
-  snprintf(buf, buf_len, "%s", tmp);
-  return SRCFD_OK;
+  return srcfd::abi_guard("srcfd_model_last_plan", [&]() -> int {
+    if (!m || !buf || buf_len == 0) { set_error("bad arguments"); return SRCFD_EINVAL; }
+    const srcfd::Plan& p = M(m)->plan;
+    const char* prec = p.precision == SRCFD_PREC_BF16 ? "bf16" : p.precision == SRCFD_PREC_F16 ? "f16" : p.precision == SRCFD_PREC_FP32 ? "fp32" : "fp32_naive";
+    char tmp[256];
+    if (p.fused)
+      snprintf(tmp, sizeof(tmp), "precision=%s encoder=%s dense_1=%s middle=%s tail=%s tail_seg=%d graph=%s", prec, p.sw.enc16 ? "enc16" : "layers",
+               p.sw.dense1_16 ? "dense1_16" : "gemm16", p.sw.mid16 ? (p.sw.mid_waves == 4 ? "mid16_4x32" : p.sw.mid_waves == 16 ? "mid16_16x32" : p.sw.mid_shape == 1 ? "mid16_8x32" : p.sw.mid_shape == 2 ? "mid16_8x64" : "mid16_4x64") : "gemm16", p.sw.tail16s ? "tail16s" : "tail16", p.tail_seg,
+               p.graph == 2 ? "replay" : p.graph == 1 ? "capture" : "eager");
+    else
+      snprintf(tmp, sizeof(tmp), "precision=%s encoder=%s dense_1=%s graph=%s", prec, p.sw.enc32 ? "enc32" : "layers",
+               p.sw.skinny32 ? "dense_skinny32" : "gemm32", p.graph == 2 ? "replay" : p.graph == 1 ? "capture" : "eager");
+    snprintf(buf, buf_len, "%s", tmp);
+    return SRCFD_OK;
+  });
 }
 
 int srcfd_model_debug_activation(srcfd_model* m, int index, void* dst, size_t bytes) {
-  if (!m || !dst || index < 0 || index > 1) { set_error("bad arguments"); return SRCFD_EINVAL; }
-  return srcfd::fused_debug_read(*M(m), index, dst, bytes);
+  return srcfd::abi_guard("srcfd_model_debug_activation", [&]() -> int {
+    if (!m || !dst || index < 0 || index > 1) { set_error("bad arguments"); return SRCFD_EINVAL; }
+    return srcfd::fused_debug_read(*M(m), index, dst, bytes);
+  });
 }
 
 int srcfd_model_save_h5(const srcfd_model* m, const char* encoder_h5, const char* decoder_h5) {
-  if (!m) { set_error("null model"); return SRCFD_EINVAL; }
-  const Model* mm = M(m);
-  try {
-    const char* paths[2] = {encoder_h5, decoder_h5};
-    int given = (encoder_h5 ? 1 : 0) + (decoder_h5 ? 1 : 0);
-    if (given == 0) { set_error("no output path"); return SRCFD_EINVAL; }
-    if ((int)mm->desc.subs.size() == 1) {
-      srcfd::save_h5_submodel(mm->desc, 0, encoder_h5 ? encoder_h5 : decoder_h5);
-    } else {
-      for (int i = 0; i < 2 && i < (int)mm->desc.subs.size(); ++i)
-        if (paths[i]) srcfd::save_h5_submodel(mm->desc, i, paths[i]);
+  return srcfd::abi_guard("srcfd_model_save_h5", [&]() -> int {
+    if (!m) { set_error("null model"); return SRCFD_EINVAL; }
+    const Model* mm = M(m);
+    try {
+      const char* paths[2] = {encoder_h5, decoder_h5};
+      int given = (encoder_h5 ? 1 : 0) + (decoder_h5 ? 1 : 0);
+      if (given == 0) { set_error("no output path"); return SRCFD_EINVAL; }
+      if ((int)mm->desc.subs.size() == 1) {
+        srcfd::save_h5_submodel(mm->desc, 0, encoder_h5 ? encoder_h5 : decoder_h5);
+      } else {
+        for (int i = 0; i < 2 && i < (int)mm->desc.subs.size(); ++i)
+          if (paths[i]) srcfd::save_h5_submodel(mm->desc, i, paths[i]);
+      }
+    } catch (const srcfd::FileError& e) {
+      set_error(e.msg);
+      return e.code;
     }
-  } catch (const srcfd::FileError& e) {
-    set_error(e.msg);
-    return e.code;
-  }
-  return SRCFD_OK;
+    return SRCFD_OK;
+  });
 }
 
 }  // extern "C"

@@ -322,130 +322,140 @@ __global__ void __launch_bounds__(128) prepare_inputs_f64(const double* __restri
 extern "C" {
 
 int srcfd_resampler_create(int device, const double* Ry, const double* Rx, int in_h, int in_w, int out_h, int out_w, srcfd_resampler** out) {
-  if (!out || !Ry || !Rx || in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0) { set_error("srcfd_resampler_create: bad arguments"); return SRCFD_EINVAL; }
-  *out = nullptr;
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
-    (void)hipGetLastError();
-    set_error("srcfd_resampler_create: no such HIP device");
-    return SRCFD_ENODEV;
-  }
-  std::unique_ptr<Resampler> r(new Resampler());
-  r->device = device; r->H = in_h; r->W = in_w; r->OH = out_h; r->OW = out_w;
-  HIPCHECK(hipSetDevice(device));
-  std::vector<double> rxt((size_t)in_w * out_w);
-  for (int o = 0; o < out_w; ++o)
-    for (int w = 0; w < in_w; ++w) rxt[(size_t)w * out_w + o] = Rx[(size_t)o * in_w + w];
-  auto is_identity = [](const double* R, int rows, int cols) {
-    if (rows != cols) return false;
-    for (int i = 0; i < rows; ++i)
-      for (int j = 0; j < cols; ++j)
-        if (std::fabs(R[(size_t)i * cols + j] - (i == j ? 1.0 : 0.0)) > 1e-13) return false;
-    return true;
-  };
-  r->ry_identity = is_identity(Ry, out_h, in_h);
-  r->rx_identity = is_identity(Rx, out_w, in_w);
-  HIPCHECK(hipMalloc(&r->d_Ry, (size_t)out_h * in_h * sizeof(double)));
-  HIPCHECK(hipMalloc(&r->d_RxT, rxt.size() * sizeof(double)));
-  HIPCHECK(hipMemcpy(r->d_Ry, Ry, (size_t)out_h * in_h * sizeof(double), hipMemcpyHostToDevice));
-  HIPCHECK(hipMemcpy(r->d_RxT, rxt.data(), rxt.size() * sizeof(double), hipMemcpyHostToDevice));
-  *out = reinterpret_cast<srcfd_resampler*>(r.release());
-  return SRCFD_OK;
+  return srcfd::abi_guard("srcfd_resampler_create", [&]() -> int {
+    if (!out || !Ry || !Rx || in_h <= 0 || in_w <= 0 || out_h <= 0 || out_w <= 0) { set_error("srcfd_resampler_create: bad arguments"); return SRCFD_EINVAL; }
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) {
+      (void)hipGetLastError();
+      set_error("srcfd_resampler_create: no such HIP device");
+      return SRCFD_ENODEV;
+    }
+    std::unique_ptr<Resampler> r(new Resampler());
+    r->device = device; r->H = in_h; r->W = in_w; r->OH = out_h; r->OW = out_w;
+    HIPCHECK(hipSetDevice(device));
+    std::vector<double> rxt((size_t)in_w * out_w);
+    for (int o = 0; o < out_w; ++o)
+      for (int w = 0; w < in_w; ++w) rxt[(size_t)w * out_w + o] = Rx[(size_t)o * in_w + w];
+    auto is_identity = [](const double* R, int rows, int cols) {
+      if (rows != cols) return false;
+      for (int i = 0; i < rows; ++i)
+        for (int j = 0; j < cols; ++j)
+          if (std::fabs(R[(size_t)i * cols + j] - (i == j ? 1.0 : 0.0)) > 1e-13) return false;
+      return true;
+    };
+    r->ry_identity = is_identity(Ry, out_h, in_h);
+    r->rx_identity = is_identity(Rx, out_w, in_w);
+    HIPCHECK(hipMalloc(&r->d_Ry, (size_t)out_h * in_h * sizeof(double)));
+    HIPCHECK(hipMalloc(&r->d_RxT, rxt.size() * sizeof(double)));
+    HIPCHECK(hipMemcpy(r->d_Ry, Ry, (size_t)out_h * in_h * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHECK(hipMemcpy(r->d_RxT, rxt.data(), rxt.size() * sizeof(double), hipMemcpyHostToDevice));
+    *out = reinterpret_cast<srcfd_resampler*>(r.release());
+    return SRCFD_OK;
+  });
 }
 
 void srcfd_resampler_destroy(srcfd_resampler* r) { delete reinterpret_cast<Resampler*>(r); }
 
 int srcfd_resample_device(srcfd_resampler* r, const float* in_dev, int n, double* out_dev, void* hip_stream) {
-  if (!r || n < 0 || (n > 0 && (!in_dev || !out_dev))) { set_error("srcfd_resample_device: bad arguments"); return SRCFD_EINVAL; }
-  if (n == 0) return SRCFD_OK;
-  Resampler* rr = reinterpret_cast<Resampler*>(r);
-  HIPCHECK(hipSetDevice(rr->device));
-  return rr->run(in_dev, n, out_dev, reinterpret_cast<hipStream_t>(hip_stream));
+  return srcfd::abi_guard("srcfd_resample_device", [&]() -> int {
+    if (!r || n < 0 || (n > 0 && (!in_dev || !out_dev))) { set_error("srcfd_resample_device: bad arguments"); return SRCFD_EINVAL; }
+    if (n == 0) return SRCFD_OK;
+    Resampler* rr = reinterpret_cast<Resampler*>(r);
+    HIPCHECK(hipSetDevice(rr->device));
+    return rr->run(in_dev, n, out_dev, reinterpret_cast<hipStream_t>(hip_stream));
+  });
 }
 
 int srcfd_predict_resampled(srcfd_model* m, srcfd_resampler* r, const float* x, int n, const float* in_affine, const float* out_affine, double* y,
                             int flags, int64_t* n_nonfinite) {
-  if (!m || !r || n < 0 || (n > 0 && (!x || !y))) { set_error("srcfd_predict_resampled: bad arguments"); return SRCFD_EINVAL; }
-  srcfd::Model* mm = reinterpret_cast<srcfd::Model*>(m);
-  Resampler* rr = reinterpret_cast<Resampler*>(r);
-  const int* os = mm->desc.out_shape();
-  if (os[0] != rr->H || os[1] != rr->W || os[2] != 1) { set_error("srcfd_predict_resampled: resampler input size != model output size"); return SRCFD_EINVAL; }
-  if (mm->device != rr->device) { set_error("srcfd_predict_resampled: model and resampler live on different devices"); return SRCFD_EINVAL; }
-  return mm->predict_host(x, n, in_affine, out_affine, nullptr, flags, n_nonfinite, [&](const float* y_dev, int first, int count) -> int {
-    int rc = rr->reserve(count);
-    if (rc) return rc;
-    rc = rr->run(y_dev, count, rr->d_out, nullptr);
-    if (rc) return rc;
-    HIPCHECK(hipMemcpyAsync(y + (size_t)first * rr->OH * rr->OW, rr->d_out, (size_t)count * rr->OH * rr->OW * sizeof(double), hipMemcpyDeviceToHost,
-                            nullptr));
-    return SRCFD_OK;
+  return srcfd::abi_guard("srcfd_predict_resampled", [&]() -> int {
+    if (!m || !r || n < 0 || (n > 0 && (!x || !y))) { set_error("srcfd_predict_resampled: bad arguments"); return SRCFD_EINVAL; }
+    srcfd::Model* mm = reinterpret_cast<srcfd::Model*>(m);
+    Resampler* rr = reinterpret_cast<Resampler*>(r);
+    const int* os = mm->desc.out_shape();
+    if (os[0] != rr->H || os[1] != rr->W || os[2] != 1) { set_error("srcfd_predict_resampled: resampler input size != model output size"); return SRCFD_EINVAL; }
+    if (mm->device != rr->device) { set_error("srcfd_predict_resampled: model and resampler live on different devices"); return SRCFD_EINVAL; }
+    return mm->predict_host(x, n, in_affine, out_affine, nullptr, flags, n_nonfinite, [&](const float* y_dev, int first, int count) -> int {
+      int rc = rr->reserve(count);
+      if (rc) return rc;
+      rc = rr->run(y_dev, count, rr->d_out, nullptr);
+      if (rc) return rc;
+      HIPCHECK(hipMemcpyAsync(y + (size_t)first * rr->OH * rr->OW, rr->d_out, (size_t)count * rr->OH * rr->OW * sizeof(double), hipMemcpyDeviceToHost,
+                              nullptr));
+      return SRCFD_OK;
+    });
   });
 }
 
 int srcfd_predict_into_solver_state(srcfd_model* m, srcfd_resampler* r, const float* x, const float* in_affine, const float* out_affine,
                                     const srcfd_solver_bc bc[3], double* Var, int flags, int64_t* n_nonfinite) {
-  if (!m || !x || !bc || !Var) { set_error("srcfd_predict_into_solver_state: bad arguments"); return SRCFD_EINVAL; }
-  srcfd::Model* mm = reinterpret_cast<srcfd::Model*>(m);
-  Resampler* rr = reinterpret_cast<Resampler*>(r);
-  const int* os = mm->desc.out_shape();
-  if (os[2] != 1) { set_error("srcfd_predict_into_solver_state: single-channel models only"); return SRCFD_EINVAL; }
-  if (rr && (os[0] != rr->H || os[1] != rr->W || mm->device != rr->device)) {
-    set_error("srcfd_predict_into_solver_state: resampler does not match the model");
-    return SRCFD_EINVAL;
-  }
-  const int ny = rr ? rr->OH : os[0], nx = rr ? rr->OW : os[1];
-  srcfd::BcDev b{};
-  std::vector<double> prof((size_t)3 * ny, 0.0);
-  bool any_profile = false;
-  for (int k = 0; k < 3; ++k) {
-    for (int s = 0; s < 4; ++s) { b.type[k][s] = bc[k].type[s]; b.value[k][s] = bc[k].value[s]; }
-    b.has_profile[k] = bc[k].left_profile != nullptr;
-    if (bc[k].left_profile) { std::memcpy(&prof[(size_t)k * ny], bc[k].left_profile, sizeof(double) * ny); any_profile = true; }
-  }
-  const size_t var_elems = (size_t)3 * (nx + 2) * (ny + 2);
-  return mm->predict_host(x, 3, in_affine, out_affine, nullptr, flags, n_nonfinite, [&](const float* y_dev, int first, int count) -> int {
-    if (first != 0 || count != 3) { set_error("srcfd_predict_into_solver_state: internal chunking error"); return SRCFD_EINVAL; }
-    const size_t need = var_elems + prof.size();
-    if (need > mm->solver_state_elems) {
-      if (mm->d_solver_state) { HIPCHECK(hipFree(mm->d_solver_state)); mm->d_solver_state = nullptr; mm->solver_state_elems = 0; }
-      HIPCHECK(hipMalloc(&mm->d_solver_state, need * sizeof(double)));
-      mm->solver_state_elems = need;
+  return srcfd::abi_guard("srcfd_predict_into_solver_state", [&]() -> int {
+    if (!m || !x || !bc || !Var) { set_error("srcfd_predict_into_solver_state: bad arguments"); return SRCFD_EINVAL; }
+    srcfd::Model* mm = reinterpret_cast<srcfd::Model*>(m);
+    Resampler* rr = reinterpret_cast<Resampler*>(r);
+    const int* os = mm->desc.out_shape();
+    if (os[2] != 1) { set_error("srcfd_predict_into_solver_state: single-channel models only"); return SRCFD_EINVAL; }
+    if (rr && (os[0] != rr->H || os[1] != rr->W || mm->device != rr->device)) {
+      set_error("srcfd_predict_into_solver_state: resampler does not match the model");
+      return SRCFD_EINVAL;
     }
-    double* d_var = mm->d_solver_state;
-    double* d_prof = any_profile ? d_var + var_elems : nullptr;
-    if (any_profile) HIPCHECK(hipMemcpyAsync(d_prof, prof.data(), prof.size() * sizeof(double), hipMemcpyHostToDevice, nullptr));
-    const unsigned blocks = (unsigned)((var_elems + 255) / 256);
-    int rc = SRCFD_OK;
-    if (rr) {
-      rc = rr->reserve(3);
-      if (rc) return rc;
-      rc = rr->run(y_dev, 3, rr->d_out, nullptr);
-      if (rc) return rc;
-      hipLaunchKernelGGL((srcfd::solver_state_f64<double>), dim3(blocks), dim3(256), 0, nullptr, rr->d_out, ny, nx, b, d_prof, d_var);
-    } else {
-      hipLaunchKernelGGL((srcfd::solver_state_f64<float>), dim3(blocks), dim3(256), 0, nullptr, y_dev, ny, nx, b, d_prof, d_var);
+    const int ny = rr ? rr->OH : os[0], nx = rr ? rr->OW : os[1];
+    srcfd::BcDev b{};
+    std::vector<double> prof((size_t)3 * ny, 0.0);
+    bool any_profile = false;
+    for (int k = 0; k < 3; ++k) {
+      for (int s = 0; s < 4; ++s) { b.type[k][s] = bc[k].type[s]; b.value[k][s] = bc[k].value[s]; }
+      b.has_profile[k] = bc[k].left_profile != nullptr;
+      if (bc[k].left_profile) { std::memcpy(&prof[(size_t)k * ny], bc[k].left_profile, sizeof(double) * ny); any_profile = true; }
     }
-    HIPCHECK(hipGetLastError());
-    HIPCHECK(hipMemcpyAsync(Var, d_var, var_elems * sizeof(double), hipMemcpyDeviceToHost, nullptr));
-    HIPCHECK(hipStreamSynchronize(nullptr));
-    return rc;
+    const size_t var_elems = (size_t)3 * (nx + 2) * (ny + 2);
+    return mm->predict_host(x, 3, in_affine, out_affine, nullptr, flags, n_nonfinite, [&](const float* y_dev, int first, int count) -> int {
+      if (first != 0 || count != 3) { set_error("srcfd_predict_into_solver_state: internal chunking error"); return SRCFD_EINVAL; }
+      const size_t need = var_elems + prof.size();
+      if (need > mm->solver_state_elems) {
+        if (mm->d_solver_state) { HIPCHECK(hipFree(mm->d_solver_state)); mm->d_solver_state = nullptr; mm->solver_state_elems = 0; }
+        HIPCHECK(hipMalloc(&mm->d_solver_state, need * sizeof(double)));
+        mm->solver_state_elems = need;
+      }
+      double* d_var = mm->d_solver_state;
+      double* d_prof = any_profile ? d_var + var_elems : nullptr;
+      if (any_profile) HIPCHECK(hipMemcpyAsync(d_prof, prof.data(), prof.size() * sizeof(double), hipMemcpyHostToDevice, nullptr));
+      const unsigned blocks = (unsigned)((var_elems + 255) / 256);
+      int rc = SRCFD_OK;
+      if (rr) {
+        rc = rr->reserve(3);
+        if (rc) return rc;
+        rc = rr->run(y_dev, 3, rr->d_out, nullptr);
+        if (rc) return rc;
+        hipLaunchKernelGGL((srcfd::solver_state_f64<double>), dim3(blocks), dim3(256), 0, nullptr, rr->d_out, ny, nx, b, d_prof, d_var);
+      } else {
+        hipLaunchKernelGGL((srcfd::solver_state_f64<float>), dim3(blocks), dim3(256), 0, nullptr, y_dev, ny, nx, b, d_prof, d_var);
+      }
+      HIPCHECK(hipGetLastError());
+      HIPCHECK(hipMemcpyAsync(Var, d_var, var_elems * sizeof(double), hipMemcpyDeviceToHost, nullptr));
+      HIPCHECK(hipStreamSynchronize(nullptr));
+      return rc;
+    });
   });
 }
 
 int srcfd_prepare_inputs_device(const double* fields_dev, int n, int h, int w, const double* Ry_dev, const double* Rx_dev, int lr,
                                 const double* train_stats_dev, int adaptive, double blend, float* x_dev, float* in_affine_dev,
                                 void* hip_stream) {
-  if (n < 0 || (n > 0 && (!fields_dev || !train_stats_dev || !x_dev || !in_affine_dev)) || h < 1 || w < 1 || h > srcfd::PREP_MAX ||
-      w > srcfd::PREP_MAX || ((Ry_dev || Rx_dev) && (lr < 1 || lr > srcfd::PREP_MAX)) || (!Ry_dev) != (!Rx_dev)) {
-    srcfd::set_error("srcfd_prepare_inputs_device: bad arguments (sides up to 32; Ry and Rx together or not at all)");
-    return SRCFD_EINVAL;
-  }
-  if (n == 0) return SRCFD_OK;
-  hipLaunchKernelGGL(srcfd::prepare_inputs_f64, dim3(n), dim3(128), 0, reinterpret_cast<hipStream_t>(hip_stream), fields_dev, h, w, Ry_dev,
-                     Rx_dev, lr, train_stats_dev, adaptive, blend, x_dev, in_affine_dev);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) { srcfd::set_error(std::string("prepare_inputs launch failed: ") + hipGetErrorString(e)); return SRCFD_EHIP; }
-  return SRCFD_OK;
+  return srcfd::abi_guard("srcfd_prepare_inputs_device", [&]() -> int {
+    if (n < 0 || (n > 0 && (!fields_dev || !train_stats_dev || !x_dev || !in_affine_dev)) || h < 1 || w < 1 || h > srcfd::PREP_MAX ||
+        w > srcfd::PREP_MAX || ((Ry_dev || Rx_dev) && (lr < 1 || lr > srcfd::PREP_MAX)) || (!Ry_dev) != (!Rx_dev)) {
+      srcfd::set_error("srcfd_prepare_inputs_device: bad arguments (sides up to 32; Ry and Rx together or not at all)");
+      return SRCFD_EINVAL;
+    }
+    if (n == 0) return SRCFD_OK;
+    hipLaunchKernelGGL(srcfd::prepare_inputs_f64, dim3(n), dim3(128), 0, reinterpret_cast<hipStream_t>(hip_stream), fields_dev, h, w, Ry_dev,
+                       Rx_dev, lr, train_stats_dev, adaptive, blend, x_dev, in_affine_dev);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { srcfd::set_error(std::string("prepare_inputs launch failed: ") + hipGetErrorString(e)); return SRCFD_EHIP; }
+    return SRCFD_OK;
+  });
 }
 
 }  // extern "C"

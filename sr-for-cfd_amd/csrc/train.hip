@@ -913,20 +913,22 @@ using srcfd::Trainer;
 extern "C" {
 
 int srcfd_trainer_create(const srcfd_model* m, int max_batch, srcfd_trainer** out) {
-  if (!m || !out || max_batch <= 0) { set_error("srcfd_trainer_create: bad arguments"); return SRCFD_EINVAL; }
-  *out = nullptr;
-  const srcfd::Model* mm = reinterpret_cast<const srcfd::Model*>(m);
-  if (mm->device < 0) { set_error("training needs a device handle"); return SRCFD_ENODEV; }
-  std::unique_ptr<Trainer> t(new Trainer());
-  try {
-    int rc = srcfd::trainer_build(*t, *mm, max_batch);
-    if (rc) return rc;
-  } catch (const std::exception& e) {
-    set_error(e.what());
-    return SRCFD_EINVAL;
-  }
-  *out = reinterpret_cast<srcfd_trainer*>(t.release());
-  return SRCFD_OK;
+  return srcfd::abi_guard("srcfd_trainer_create", [&]() -> int {
+    if (!m || !out || max_batch <= 0) { set_error("srcfd_trainer_create: bad arguments"); return SRCFD_EINVAL; }
+    *out = nullptr;
+    const srcfd::Model* mm = reinterpret_cast<const srcfd::Model*>(m);
+    if (mm->device < 0) { set_error("training needs a device handle"); return SRCFD_ENODEV; }
+    std::unique_ptr<Trainer> t(new Trainer());
+    try {
+      int rc = srcfd::trainer_build(*t, *mm, max_batch);
+      if (rc) return rc;
+    } catch (const std::exception& e) {
+      set_error(e.what());
+      return SRCFD_EINVAL;
+    }
+    *out = reinterpret_cast<srcfd_trainer*>(t.release());
+    return SRCFD_OK;
+  });
 }
 
 void srcfd_trainer_destroy(srcfd_trainer* t) { delete reinterpret_cast<Trainer*>(t); }
@@ -934,62 +936,68 @@ void srcfd_trainer_destroy(srcfd_trainer* t) { delete reinterpret_cast<Trainer*>
 int64_t srcfd_trainer_num_params(const srcfd_trainer* t) { return t ? reinterpret_cast<const Trainer*>(t)->n_params : 0; }
 
 int srcfd_trainer_get_params(const srcfd_trainer* t, float* params_host) {
-  if (!t || !params_host) { set_error("bad arguments"); return SRCFD_EINVAL; }
-  const Trainer* tt = reinterpret_cast<const Trainer*>(t);
-  std::memcpy(params_host, tt->init_params.data(), tt->init_params.size() * sizeof(float));
-  return SRCFD_OK;
+  return srcfd::abi_guard("srcfd_trainer_get_params", [&]() -> int {
+    if (!t || !params_host) { set_error("bad arguments"); return SRCFD_EINVAL; }
+    const Trainer* tt = reinterpret_cast<const Trainer*>(t);
+    std::memcpy(params_host, tt->init_params.data(), tt->init_params.size() * sizeof(float));
+    return SRCFD_OK;
+  });
 }
 
 int srcfd_trainer_forward_backward(srcfd_trainer* t, const float* params_dev, const float* x_dev, const float* y_dev, int n, float loss_scale,
                                    float* grads_dev, double* sse_dev, void* hip_stream) {
-  if (!t || !params_dev || !x_dev || !y_dev || !grads_dev) { set_error("bad arguments"); return SRCFD_EINVAL; }
-  Trainer& tt = *reinterpret_cast<Trainer*>(t);
-  hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
-  if (!tt.use_graph || n <= 0 || n > tt.max_batch) return srcfd::trainer_step(tt, params_dev, x_dev, y_dev, n, loss_scale, grads_dev, sse_dev, s);
-  HIPCHECK(hipSetDevice(tt.device));
-  const size_t xe = (size_t)n * tt.x_elems, ye = (size_t)n * tt.y_elems;
-  if (((uintptr_t)x_dev | (uintptr_t)y_dev) % 16 == 0 && xe % 4 == 0 && ye % 4 == 0) {
-    const int64_t nx = (int64_t)(xe / 4), ny = (int64_t)(ye / 4);
-    hipLaunchKernelGGL(srcfd::stage_xy_f32, dim3((unsigned)std::min<int64_t>(2048, (nx + ny + 255) / 256)), dim3(256), 0, s,
-                       reinterpret_cast<const float4*>(x_dev), reinterpret_cast<float4*>(tt.d_xs), nx, reinterpret_cast<const float4*>(y_dev),
-                       reinterpret_cast<float4*>(tt.d_ys), ny);
-  } else {
-    HIPCHECK(hipMemcpyAsync(tt.d_xs, x_dev, xe * sizeof(float), hipMemcpyDeviceToDevice, s));
-    HIPCHECK(hipMemcpyAsync(tt.d_ys, y_dev, ye * sizeof(float), hipMemcpyDeviceToDevice, s));
-  }
-  Trainer::StepKey key;
-  key.params = params_dev; key.grads = grads_dev; key.sse = sse_dev; key.n = n; key.loss_scale = loss_scale;
-  Trainer::StepGraph* slot = nullptr;
-  for (auto& g : tt.graphs) if (g.key == key) slot = &g;
-  if (!slot && tt.graphs.size() < 8) { tt.graphs.emplace_back(); slot = &tt.graphs.back(); slot->key = key; }
-  if (slot && slot->exec) { HIPCHECK(hipGraphLaunch(slot->exec, s)); return SRCFD_OK; }
-  if (slot && ++slot->seen == 2) {  // every one-time set-up (function attributes, ...) happened on the first, plain pass
-    HIPCHECK(hipStreamBeginCapture(tt.cap_stream, hipStreamCaptureModeThreadLocal));
-    int rc = srcfd::trainer_step(tt, params_dev, tt.d_xs, tt.d_ys, n, loss_scale, grads_dev, sse_dev, tt.cap_stream);
-    hipGraph_t g = nullptr;
-    hipError_t e = hipStreamEndCapture(tt.cap_stream, &g);
-    if (rc == SRCFD_OK && e == hipSuccess && g) {
-      e = hipGraphInstantiate(&slot->exec, g, nullptr, nullptr, 0);
-      (void)hipGraphDestroy(g);
-      if (e == hipSuccess) { HIPCHECK(hipGraphLaunch(slot->exec, s)); return SRCFD_OK; }
-      slot->exec = nullptr;
-    } else if (g) (void)hipGraphDestroy(g);
-    (void)hipGetLastError();  // capture not possible here: plain launches from now on for this key
-    slot->seen = 3;
-  }
-  return srcfd::trainer_step(tt, params_dev, tt.d_xs, tt.d_ys, n, loss_scale, grads_dev, sse_dev, s);
+  return srcfd::abi_guard("srcfd_trainer_forward_backward", [&]() -> int {
+    if (!t || !params_dev || !x_dev || !y_dev || !grads_dev) { set_error("bad arguments"); return SRCFD_EINVAL; }
+    Trainer& tt = *reinterpret_cast<Trainer*>(t);
+    hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+    if (!tt.use_graph || n <= 0 || n > tt.max_batch) return srcfd::trainer_step(tt, params_dev, x_dev, y_dev, n, loss_scale, grads_dev, sse_dev, s);
+    HIPCHECK(hipSetDevice(tt.device));
+    const size_t xe = (size_t)n * tt.x_elems, ye = (size_t)n * tt.y_elems;
+    if (((uintptr_t)x_dev | (uintptr_t)y_dev) % 16 == 0 && xe % 4 == 0 && ye % 4 == 0) {
+      const int64_t nx = (int64_t)(xe / 4), ny = (int64_t)(ye / 4);
+      hipLaunchKernelGGL(srcfd::stage_xy_f32, dim3((unsigned)std::min<int64_t>(2048, (nx + ny + 255) / 256)), dim3(256), 0, s,
+                         reinterpret_cast<const float4*>(x_dev), reinterpret_cast<float4*>(tt.d_xs), nx, reinterpret_cast<const float4*>(y_dev),
+                         reinterpret_cast<float4*>(tt.d_ys), ny);
+    } else {
+      HIPCHECK(hipMemcpyAsync(tt.d_xs, x_dev, xe * sizeof(float), hipMemcpyDeviceToDevice, s));
+      HIPCHECK(hipMemcpyAsync(tt.d_ys, y_dev, ye * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    Trainer::StepKey key;
+    key.params = params_dev; key.grads = grads_dev; key.sse = sse_dev; key.n = n; key.loss_scale = loss_scale;
+    Trainer::StepGraph* slot = nullptr;
+    for (auto& g : tt.graphs) if (g.key == key) slot = &g;
+    if (!slot && tt.graphs.size() < 8) { tt.graphs.emplace_back(); slot = &tt.graphs.back(); slot->key = key; }
+    if (slot && slot->exec) { HIPCHECK(hipGraphLaunch(slot->exec, s)); return SRCFD_OK; }
+    if (slot && ++slot->seen == 2) {  // every one-time set-up (function attributes, ...) happened on the first, plain pass
+      HIPCHECK(hipStreamBeginCapture(tt.cap_stream, hipStreamCaptureModeThreadLocal));
+      int rc = srcfd::trainer_step(tt, params_dev, tt.d_xs, tt.d_ys, n, loss_scale, grads_dev, sse_dev, tt.cap_stream);
+      hipGraph_t g = nullptr;
+      hipError_t e = hipStreamEndCapture(tt.cap_stream, &g);
+      if (rc == SRCFD_OK && e == hipSuccess && g) {
+        e = hipGraphInstantiate(&slot->exec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e == hipSuccess) { HIPCHECK(hipGraphLaunch(slot->exec, s)); return SRCFD_OK; }
+        slot->exec = nullptr;
+      } else if (g) (void)hipGraphDestroy(g);
+      (void)hipGetLastError();  // capture not possible here: plain launches from now on for this key
+      slot->seen = 3;
+    }
+    return srcfd::trainer_step(tt, params_dev, tt.d_xs, tt.d_ys, n, loss_scale, grads_dev, sse_dev, s);
+  });
 }
 
 int srcfd_adam_step(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, int64_t n, int step, float lr, float beta1,
                     float beta2, float eps, void* hip_stream) {
-  if (!params_dev || !grads_dev || !m_dev || !v_dev || n < 0 || step < 1) { set_error("bad arguments"); return SRCFD_EINVAL; }
-  if (n == 0) return SRCFD_OK;
-  const float alpha_t = (float)((double)lr * std::sqrt(1.0 - std::pow((double)beta2, step)) / (1.0 - std::pow((double)beta1, step)));
-  hipLaunchKernelGGL(srcfd::adam_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), params_dev,
-                     grads_dev, m_dev, v_dev, n, alpha_t, beta1, beta2, eps);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) { set_error(hipGetErrorString(e)); return SRCFD_EHIP; }
-  return SRCFD_OK;
+  return srcfd::abi_guard("srcfd_adam_step", [&]() -> int {
+    if (!params_dev || !grads_dev || !m_dev || !v_dev || n < 0 || step < 1) { set_error("bad arguments"); return SRCFD_EINVAL; }
+    if (n == 0) return SRCFD_OK;
+    const float alpha_t = (float)((double)lr * std::sqrt(1.0 - std::pow((double)beta2, step)) / (1.0 - std::pow((double)beta1, step)));
+    hipLaunchKernelGGL(srcfd::adam_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, reinterpret_cast<hipStream_t>(hip_stream), params_dev,
+                       grads_dev, m_dev, v_dev, n, alpha_t, beta1, beta2, eps);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error(hipGetErrorString(e)); return SRCFD_EHIP; }
+    return SRCFD_OK;
+  });
 }
 
 }  // extern "C"

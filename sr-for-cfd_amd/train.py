@@ -18,11 +18,15 @@ from . import _lib as L
 from .engine import SRModel
 
 
-def allreduce_sum_(flat_grads) -> None:
-    """The step's only collective: in-place SUM over ranks of the flat gradient tensor."""
+def allreduce_sum_(flat_grads, async_op: bool = False):
+    """The step's only collective: in-place SUM over ranks of the flat gradient tensor.
+    async_op=True returns the collective's work handle (None with one rank): with the RCCL backend the reduction runs on
+    the backend's own stream behind an event of the caller's stream, and `handle.wait()` makes the caller's STREAM wait
+    for it, not the host -- whatever the host enqueues in between (the next batch's staging) is not held up."""
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
+        return dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM, async_op=async_op) if async_op else dist.all_reduce(flat_grads, op=dist.ReduceOp.SUM)
+    return None
 
 
 def world_size() -> int:
@@ -112,23 +116,22 @@ class Trainer:
     def step(self, x, y, global_batch: Optional[int] = None, return_loss: bool = True):
         """One optimisation step on this rank's micro-batch (contiguous float32 CUDA tensors).  Returns
         the global mean-squared error of the batch (like Keras' `recon_loss`); with return_loss=False
-        nothing is read back (no host synchronisation) and the squared-error sum stays in `self.sse`."""
-        import torch
+        nothing is read back (no host synchronisation) and the squared-error sum stays in `self.sse`.
+        global_batch: samples of the step over ALL ranks (the loss normalisation).  None = this rank's count x the world
+        size, i.e. equal micro-batches; a ragged global batch (Keras' last batch of an epoch) must be passed explicitly --
+        every rank knows it from `epoch_batches_global` without a collective (no per-step all-reduce + host read-back)."""
         import torch.distributed as dist
         n = int(x.shape[0])
         w = world_size()
         if global_batch is None:
-            if w > 1:
-                cnt = torch.tensor([n], dtype=torch.int64, device=self.device)
-                dist.all_reduce(cnt)
-                global_batch = int(cnt.item())
-            else:
-                global_batch = n
+            global_batch = n * w
         self.grads.zero_()
         self.sse.zero_()
         if n:
             self.forward_backward(x, y, global_batch)
-        allreduce_sum_(self.grads)
+        work = allreduce_sum_(self.grads, async_op=True)
+        if work is not None:
+            work.wait()          # stream-side wait (RCCL): Adam follows the reduction, the host runs on
         self.apply_adam()
         if not return_loss:
             return None
@@ -173,12 +176,33 @@ def fit(trainer: Trainer, x_lr: np.ndarray, x_hr: np.ndarray, epochs: int, batch
     ys = torch.from_numpy(np.ascontiguousarray(x_hr, np.float32)).to(trainer.device)
     history = []
     epoch_loss = torch.zeros(1, dtype=torch.float64, device=trainer.device)
+    # Input pipeline (`shuffle(len).batch(8)`, c558): the gather of batch k + 1 runs on a side stream while step k (kernels,
+    # gradient all-reduce, Adam) runs on the main one; the main stream waits for a batch's event only, never the host.
+    main = torch.cuda.current_stream(trainer.device)
+    side = torch.cuda.Stream(device=trainer.device)
+    side.wait_stream(main)       # xs / ys were uploaded on the main stream
+
+    def gather(idx):
+        with torch.cuda.stream(side):
+            sel = torch.from_numpy(np.ascontiguousarray(idx)).to(trainer.device, non_blocking=True)
+            xb, yb = xs.index_select(0, sel), ys.index_select(0, sel)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return xb, yb, ev
+
     for ep in range(epochs):
         epoch_loss.zero_()
         steps = 0
-        for idx, gb in epoch_batches_global(len(xs), batch_size, ep, seed, r, w):
-            sel = torch.from_numpy(np.ascontiguousarray(idx)).to(trainer.device)
-            trainer.step(xs[sel].contiguous(), ys[sel].contiguous(), global_batch=gb, return_loss=False)
+        batches = list(epoch_batches_global(len(xs), batch_size, ep, seed, r, w))
+        nxt = gather(batches[0][0]) if batches else None
+        for i, (idx, gb) in enumerate(batches):
+            xb, yb, ev = nxt
+            if i + 1 < len(batches):
+                nxt = gather(batches[i + 1][0])
+            main.wait_event(ev)
+            xb.record_stream(main)
+            yb.record_stream(main)
+            trainer.step(xb, yb, global_batch=gb, return_loss=False)
             epoch_loss += trainer.sse / (gb * trainer.out_elems)   # this rank's share of the batch loss, on the device
             steps += 1
         if w > 1:

@@ -1,5 +1,6 @@
 """CPU tests of the file formats and the C-ABI surface (no compute calls)."""
 import ctypes
+import importlib
 import os
 import re
 import subprocess
@@ -424,3 +425,41 @@ def test_corrupted_weight_files_under_address_sanitizer(tmp_path):
         assert out.returncode == 0, out.stderr[-3000:]
         ok, bad, _ = map(int, out.stdout.split())
         assert ok + bad == len(paths[lo:lo + 100])
+
+
+def test_every_int_entry_point_runs_inside_the_abi_guard():
+    """`never throws across the ABI` (include/srcfd.h; SURVEY.md 8b errors) is enforced structurally: every multi-line
+    int-returning extern "C" definition in csrc/ opens with srcfd::abi_guard (VERDICT r3 item 7: resample.hip and most of
+    train.hip had new / std::vector with no try / catch)."""
+    import re
+    src = os.path.join(ROOT, "sr-for-cfd_amd", "csrc")
+    seen = 0
+    for f in sorted(os.listdir(src)):
+        if not f.endswith((".hip", ".cpp")):
+            continue
+        text = open(os.path.join(src, f)).read()
+        for m in re.finditer(r'^(?:extern "C" )?int (srcfd_\w+)\([^;{]*\) \{\n(.*)\n', text, re.M):
+            seen += 1
+            assert "abi_guard(\"" + m.group(1) + "\"" in m.group(2), (f, m.group(1), m.group(2))
+    assert seen >= 40, seen
+
+
+@pytest.mark.gpu
+def test_allocation_failure_is_a_status_not_a_crash(srcfd):
+    """An absurd resampling matrix (2^30 x 2^30 doubles) cannot be allocated: std::bad_alloc / length_error inside
+    srcfd_resampler_create must come back as a negative status with a message, through the ABI guard."""
+    import ctypes as C
+    from conftest import require_gpu
+    require_gpu(srcfd)
+    L = importlib.import_module("sr-for-cfd_amd._lib")
+    dummy = np.zeros(8, np.float64)
+    h = C.c_void_p()
+    rc = L.lib.srcfd_resampler_create(0, dummy.ctypes.data_as(C.c_void_p), dummy.ctypes.data_as(C.c_void_p), 1, 1 << 30, 1, 1 << 30, C.byref(h))
+    assert rc in (L.ENOMEM, L.EINVAL) and not h.value, rc
+    msg = L.lib.srcfd_last_error().decode()
+    assert "srcfd_resampler_create" in msg, msg
+    # the library is still usable afterwards: a sane resampler comes up
+    eye = np.eye(4)
+    rc = L.lib.srcfd_resampler_create(0, eye.ctypes.data_as(C.c_void_p), eye.ctypes.data_as(C.c_void_p), 4, 4, 4, 4, C.byref(h))
+    assert rc == 0 and h.value
+    L.lib.srcfd_resampler_destroy(h)
