@@ -123,19 +123,15 @@ int srcfd_model_has_fused_path(const srcfd_model* m);
  * Optional fused pre/post-processing, per sample i (both may be NULL):
  *   in_affine[2i..2i+1]  = (mean, std): x := (x - mean) / std in float32
  *       (standardize_with_stats, PyCFD_ML_accelerated.py:665-668; std==0 -> 1e-8)
- *   out_affine[2i..2i+1] = (mean, std): y := y * std + mean in float32, two
- *       roundings like numpy (inverse_standardize, PyCFD_ML_accelerated.py:671-673)
+ *   out_affine[2i..2i+1] = (mean, std): y := y * std + mean in float32
+ *       (inverse_standardize, PyCFD_ML_accelerated.py:671-673).  SRCFD_PREC_FP32 (the parity path): two roundings,
+ *       bit for bit numpy's float32 result; the 16-bit precisions fuse the two into ONE fma (<= 1 ulp from it)
  * flags: SRCFD_FLAG_NAN_GUARD zero-fills NaN/Inf in y and counts them in
  * *n_nonfinite (PyCFD_ML_accelerated.py:869-876). */
 #define SRCFD_FLAG_NAN_GUARD 1
 int srcfd_predict(srcfd_model* m, const float* x, int n, const float* in_affine, const float* out_affine,
                   float* y, int flags, int64_t* n_nonfinite);
 
-/* Device-resident variant for the batched path: x_dev float32 (n,h,w,c),
- * affines float32 device arrays or NULL, y_dev of dtype out_dtype (SRCFD_F32,
- * SRCFD_BF16 or SRCFD_F16), nonfinite_dev an optional device int64 counter
- * that is ADDED to.  Enqueues on hip_stream (a hipStream_t, NULL = default
- * stream) and returns without synchronising. */
 /* Page-locked host memory for the arrays handed to srcfd_predict.  A result (y) that lives in such memory -- from here, or any
  * hipHostMalloc / hipHostRegister'ed range -- is filled at the PCIe rate with the copy of one chunk overlapping the kernels of the
  * next; a pageable result is staged by the runtime (about 45 GB/s, nothing overlaps) and, when freshly allocated, also pays its
@@ -143,6 +139,11 @@ int srcfd_predict(srcfd_model* m, const float* x, int n, const float* in_affine,
 int srcfd_host_alloc(size_t bytes, void** out);
 void srcfd_host_free(void* p);
 
+/* Device-resident variant for the batched path: x_dev float32 (n,h,w,c),
+ * affines float32 device arrays or NULL, y_dev of dtype out_dtype (SRCFD_F32,
+ * SRCFD_BF16 or SRCFD_F16), nonfinite_dev an optional device int64 counter
+ * that is ADDED to.  Enqueues on hip_stream (a hipStream_t, NULL = default
+ * stream) and returns without synchronising. */
 int srcfd_predict_device(srcfd_model* m, const void* x_dev, int n, const float* in_affine_dev,
                          const float* out_affine_dev, void* y_dev, int out_dtype, int flags,
                          int64_t* nonfinite_dev, void* hip_stream);

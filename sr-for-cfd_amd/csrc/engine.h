@@ -44,7 +44,7 @@ struct Switches {
   bool dense1_16 = true; // SRCFD_DENSE1=0: dense_1 on the generic 16-bit GEMM
   bool enc32 = true;     // SRCFD_NO_ENC32=1: layer-by-layer f32 encoder
   bool skinny32 = true;  // SRCFD_NO_DENSE_SKINNY=1: dense_1 on the generic f32 GEMM
-  bool tail16s = false;  // SRCFD_TAIL=s: the software-pipelined 8-wave tail kernel (kernels_tail16.hip) instead of the 16-wave, stage-by-stage one (measured slower)
+  bool tail16s = false;  // SRCFD_TAIL=s: the software-pipelined 8-wave tail kernel (kernels_tail16s.hip) instead of the 16-wave, stage-by-stage one (measured slower)
   int mid_waves = 0;     // SRCFD_MID_WAVES: other workgroup shapes of mid16 (4, 16: waves per workgroup at 32 pixels per wave); 0 = the shape mid_shape selects
   int mid_order = 0;     // SRCFD_MID_ORDER=1: mid16's workgroups dispatched with output phases 0 / 3 and 1 / 2 alternating instead of phase by phase
   int tail_seg = 0;      // SRCFD_TAIL_SEG: segments per sample of the 16-bit tail (1, 2, 5, 10, 25); 0 = chosen per batch

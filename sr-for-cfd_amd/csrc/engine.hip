@@ -632,12 +632,23 @@ int Model::predict_host(const float* x, int n, const float* aff_in, const float*
   // Is the destination page-locked (srcfd_host_alloc, hipHostMalloc / hipHostRegister)?  Then the device-to-host copy of chunk i runs on
   // a second stream while chunk i + 1 is computed (two result buffers, events both ways) and the whole call moves at the PCIe rate;
   // into pageable memory the copy is staged by the runtime and nothing overlaps (one buffer, as before).
+  // The WHOLE range [y, y + n out_elems) must be page-locked, not managed, and one allocation: its first and its last byte are asked
+  // (a range that starts in a registered block and runs past its end, or managed memory, takes the staged path).
   bool pinned = false;
   if (y && !sink) {
-    hipPointerAttribute_t at;
-    if (hipPointerGetAttributes(&at, y) == hipSuccess) pinned = at.type == hipMemoryTypeHost;
+    hipPointerAttribute_t a0, a1;
+    const char* last = reinterpret_cast<const char*>(y) + (size_t)n * out_elems * sizeof(float) - 1;
+    if (hipPointerGetAttributes(&a0, y) == hipSuccess && hipPointerGetAttributes(&a1, last) == hipSuccess)
+      pinned = a0.type == hipMemoryTypeHost && a1.type == hipMemoryTypeHost && !a0.isManaged && !a1.isManaged &&
+               reinterpret_cast<const char*>(a1.hostPointer) - reinterpret_cast<const char*>(a0.hostPointer) == last - reinterpret_cast<const char*>(y);
     else (void)hipGetLastError();
   }
+  // On the overlapped path an error exit must not leave earlier chunks' copies into the caller's array in flight (the caller drops
+  // the array, the pool hands the buffer to the next call): whatever way this function is left, both streams are drained first.
+  struct Drain {
+    bool armed; hipStream_t* cs;
+    ~Drain() { if (armed) { if (*cs) (void)hipStreamSynchronize(*cs); (void)hipStreamSynchronize(nullptr); } }
+  } drain{pinned, &copy_stream};
   int chunk = std::min(n, pinned ? 128 : 256);
   if (chunk > stage_chunk || (pinned && !d_y_stage2)) {
     chunk = std::max(chunk, stage_chunk);
@@ -685,7 +696,7 @@ int Model::predict_host(const float* x, int n, const float* aff_in, const float*
       HIPCHECK(hipStreamSynchronize(nullptr));
     }
   }
-  if (pinned && !sink) { HIPCHECK(hipStreamSynchronize(copy_stream)); HIPCHECK(hipStreamSynchronize(nullptr)); }
+  if (pinned && !sink) { HIPCHECK(hipStreamSynchronize(copy_stream)); HIPCHECK(hipStreamSynchronize(nullptr)); drain.armed = false; }
   if (n_nonfinite) {
     unsigned long long v = 0;
     HIPCHECK(hipMemcpy(&v, d_nonfinite, sizeof(v), hipMemcpyDeviceToHost));

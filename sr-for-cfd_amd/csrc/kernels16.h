@@ -96,7 +96,7 @@ hipError_t launch_enc_conv1_16(bool f16, const float* x, const float* affine, co
 hipError_t launch_gemm16(bool f16, const GemmDesc& d, const uint16_t* X, const uint16_t* Wt, int Kpad, const float* bias, uint16_t* Y,
                          float* part, int splits, hipStream_t s);
 hipError_t launch_tail16(bool f16, const TailParams& p, int blocks, hipStream_t s);    // shipped kernel (kernels_bf16.hip): 16 waves, stage by stage
-hipError_t launch_tail16s(bool f16, const TailParams& p, int blocks, hipStream_t s);   // second implementation (kernels_tail16.hip, SRCFD_TAIL=s): 8 waves, MFMAs inside the swish stream
+hipError_t launch_tail16s(bool f16, const TailParams& p, int blocks, hipStream_t s);   // second implementation (kernels_tail16s.hip, SRCFD_TAIL=s): 8 waves, MFMAs inside the swish stream
 int tail_lds_bytes();
 
 }  // namespace srcfd

@@ -1,12 +1,13 @@
-// tail16 (round 3): ConvT#2 -> ConvT#3 -> ConvT#4 -> 3x3 output conv + de-standardise + NaN guard of the 16-bit path in one
-// streaming launch (sr-ae-conv.ipynb:c283-286, PyCFD_ML_accelerated.py:671-673,869-876).
+// tail16s: the SECOND implementation of the 16-bit tail (ConvT#2 -> ConvT#3 -> ConvT#4 -> 3x3 output conv + de-standardise + NaN
+// guard in one streaming launch; sr-ae-conv.ipynb:c283-286, PyCFD_ML_accelerated.py:671-673,869-876).
+// NOT the shipped kernel: the default is `tail16` in kernels_bf16.hip; this one runs only under SRCFD_TAIL=s (the A/B arm of the
+// parity tests, which compare the two bit for bit) and measured 15 % slower (experiments: 4.1c).
 //
-// Same data flow and LDS layout as the round-2 kernel (kernels_bf16.hip, kept as the second implementation the parity tests
-// compare this one with bit for bit): one workgroup per CU walks its samples as one tall image in strips of one 50-level row;
+// Same data flow and LDS layout as tail16: one workgroup per CU walks its samples as one tall image in strips of one 50-level row;
 // round r runs A (ConvT#2, strip r, global -> 100-level LDS tile), BC (ConvT#3 -> ConvT#4 in registers, strip r-1, -> 18-row
 // ring of the 400x400x8 level) and D (banded-MFMA output conv of strip r-2 from the ring) between two barriers.
 //
-// What is new is HOW a round is issued (tools/microbench9.hip, profiles/r03):
+// What differs is HOW a round is issued (round-3 experiment; tools/microbench9.hip, profiles/r03):
 //  * 8 waves of 256 registers instead of 16 of 128.  The kernel is bound by the vector unit's swish stream (two transcendentals
 //    per activation); at two waves per SIMD that stream runs within 2 % of its four-wave rate, and a wave now has the registers to
 //    hold the NEXT stage's operands and accumulators beside the accumulator it is activating.

@@ -1,5 +1,5 @@
-// LDS layout of the fused 16-bit tail (shared by its two implementations: kernels_tail16.hip, the shipped one, and the round-2
-// kernel in kernels_bf16.hip that the parity tests compare it with bit for bit).
+// LDS layout of the fused 16-bit tail, shared by its two implementations: `tail16` in kernels_bf16.hip (the shipped kernel) and
+// `tail16s` in kernels_tail16s.hip (SRCFD_TAIL=s, the A/B arm the parity tests compare it with bit for bit; measured slower).
 //  ring (400-level, 16 B per pixel): a row is 8 planes (x & 7) of 52 granules (1 + (x >> 3); granules 0 and 51 stay zero: the
 //    SAME padding of the output conv at the left / right image edge, read like any other pixel -- no per-lane edge tests).
 //    BC writes a wave of pixels 4 apart in x (-> consecutive granules of two planes, 2-way at worst); D reads 16 tiles 8 apart

@@ -54,56 +54,87 @@ def layers_from_weights(enc_w: Optional[Dict[str, np.ndarray]], dec_w: Optional[
 class _PinnedPool:
     """Recycling pool of page-locked result buffers (srcfd_host_alloc).  `empty(shape)` returns a float32 ndarray over a pool buffer;
     the buffer goes back to the pool when the array and every view of it are gone (a weakref finalizer on the ctypes object all
-    the views hang from).  Bounded: at most `cap_bytes` are kept for reuse, the rest is freed.  Small results (< `min_bytes`) and
-    hosts where the allocation fails use ordinary numpy memory.  SRCFD_RESULT_POOL=0 switches the pool off."""
+    the views hang from).
+    * Sizes are rounded up to a few classes (four per octave: at most 25 % over-allocation), so callers with varying batch sizes
+      share buffers instead of growing one bucket per exact size.
+    * Bounded: at most `cap_bytes` stay cached (default 1 GiB, `SRCFD_RESULT_POOL_MB`); a released buffer that does not fit EVICTS the
+      least recently used cached ones to make room (it is the most likely to be asked for again) instead of being freed itself.
+    * Small results (< `min_bytes`) and hosts where the allocation fails use ordinary numpy memory.  SRCFD_RESULT_POOL=0 switches
+      the pool off."""
 
-    def __init__(self, min_bytes: int = 4 << 20, cap_bytes: int = 4 << 30):
+    def __init__(self, min_bytes: int = 4 << 20, cap_bytes: Optional[int] = None):
         import threading
-        self.min_bytes, self.cap_bytes = min_bytes, cap_bytes
-        self.free = {}            # nbytes -> [ptr, ...]
+        from collections import OrderedDict
+        if cap_bytes is None:
+            try:
+                cap_bytes = int(float(os.environ.get("SRCFD_RESULT_POOL_MB", "1024")) * (1 << 20))
+            except ValueError:
+                cap_bytes = 1 << 30
+        self.min_bytes, self.cap_bytes = min_bytes, max(0, cap_bytes)
+        self.free = OrderedDict()   # ptr -> class bytes, least recently released first
         self.cached = 0
         self.lock = threading.Lock()
         self.enabled = os.environ.get("SRCFD_RESULT_POOL", "1") not in ("0", "")
-        self.stats = {"allocated": 0, "reused": 0, "fallback": 0}
+        self.stats = {"allocated": 0, "reused": 0, "fallback": 0, "evicted": 0}
 
-    def _release(self, ptr: int, nbytes: int) -> None:
+    @staticmethod
+    def size_class(nbytes: int) -> int:
+        """nbytes rounded up to a multiple of a quarter of its leading power of two (and of 4 KiB)."""
+        step = max(4096, 1 << max(nbytes.bit_length() - 3, 0))
+        return -(-nbytes // step) * step
+
+    def _release(self, ptr: int, cls_bytes: int) -> None:
+        drop = []
         with self.lock:
-            if self.cached + nbytes <= self.cap_bytes:
-                self.free.setdefault(nbytes, []).append(ptr)
-                self.cached += nbytes
-                return
-        L.lib.srcfd_host_free(C.c_void_p(ptr))
+            if cls_bytes > self.cap_bytes:
+                drop.append(ptr)
+            else:
+                while self.cached + cls_bytes > self.cap_bytes and self.free:
+                    old, ob = self.free.popitem(last=False)
+                    self.cached -= ob
+                    self.stats["evicted"] += 1
+                    drop.append(old)
+                self.free[ptr] = cls_bytes
+                self.cached += cls_bytes
+        for q in drop:
+            L.lib.srcfd_host_free(C.c_void_p(q))
 
     def empty(self, shape) -> np.ndarray:
         import weakref
         nbytes = int(np.prod(shape)) * 4
         if not self.enabled or nbytes < self.min_bytes:
             return np.empty(shape, dtype=np.float32)
+        cls_bytes = self.size_class(nbytes)
         ptr = None
         with self.lock:
-            lst = self.free.get(nbytes)
-            if lst:
-                ptr = lst.pop()
-                self.cached -= nbytes
+            for q in reversed(self.free):            # most recently released first: its pages are the warmest
+                if self.free[q] == cls_bytes:
+                    ptr = q
+                    break
+            if ptr is not None:
+                del self.free[ptr]
+                self.cached -= cls_bytes
                 self.stats["reused"] += 1
         if ptr is None:
             out = C.c_void_p()
-            if L.lib.srcfd_host_alloc(nbytes, C.byref(out)) != 0 or not out.value:
-                self.stats["fallback"] += 1
+            ok = L.lib.srcfd_host_alloc(cls_bytes, C.byref(out)) == 0 and bool(out.value)
+            with self.lock:
+                self.stats["allocated" if ok else "fallback"] += 1
+            if not ok:
                 return np.empty(shape, dtype=np.float32)
             ptr = out.value
-            self.stats["allocated"] += 1
         buf = (C.c_char * nbytes).from_address(ptr)
-        weakref.finalize(buf, self._release, ptr, nbytes)
+        weakref.finalize(buf, self._release, ptr, cls_bytes)
         return np.frombuffer(buf, dtype=np.float32).reshape(shape)
 
     def trim(self) -> None:
         """Frees every cached buffer (buffers still referenced by arrays stay alive until those die)."""
         with self.lock:
-            items, self.free, self.cached = self.free, {}, 0
-        for lst in items.values():
-            for ptr in lst:
-                L.lib.srcfd_host_free(C.c_void_p(ptr))
+            items = list(self.free)
+            self.free.clear()
+            self.cached = 0
+        for ptr in items:
+            L.lib.srcfd_host_free(C.c_void_p(ptr))
 
 
 _result_pool = _PinnedPool()
