@@ -146,7 +146,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "fp32", "fp32x3"])
     ap.add_argument("--out-dtype", default="f32", choices=["f32", "bf16", "f16"])
     ap.add_argument("--fields", type=int, default=FIELDS)
     ap.add_argument("--workload", default="sr", choices=["sr", "tiled"],
@@ -319,7 +319,7 @@ class Job:
         # One-time set-up of every leg's precision (operand packs, activation workspaces) happens here, through the ABI's
         # explicit reserve call, not lazily inside a leg's first warm-up step: a leg then starts on a GPU that the previous
         # leg has just left, instead of one that idled through host-side weight packing and hipMalloc.
-        for prec in dict.fromkeys(([] if args.no_extras or args.precision == "fp32" else ["fp32"]) + [args.precision]):
+        for prec in dict.fromkeys(([] if args.no_extras or args.precision in ("fp32", "fp32x3") else ["fp32", "fp32x3"]) + [args.precision]):
             self.model.precision = prec
             self.model.reserve(self.n)
         self.y_out = {}
@@ -574,7 +574,12 @@ class Job:
         for n in (3, self.n):
             x = self.x_h[:n]
             ai, ao = self.ain_h[:n], self.aout_h[:n]
-            self.model.predict(x, in_affine=ai, out_affine=ao, nan_guard=True)
+            eng = importlib.import_module("sr-for-cfd_amd.engine")
+            eng._result_pool.trim()                      # the first call below pays the page-locked allocation (hipHostMalloc)
+            t0 = time.perf_counter()
+            y = self.model.predict(x, in_affine=ai, out_affine=ao, nan_guard=True)
+            first = time.perf_counter() - t0
+            del y
             fresh = []
             for _ in range(3):
                 t0 = time.perf_counter()
@@ -587,12 +592,14 @@ class Job:
                 t0 = time.perf_counter()
                 self.model.predict(x, in_affine=ai, out_affine=ao, nan_guard=True, out=yp)
                 reused.append(time.perf_counter() - t0)
-            out[f"samples_{n}"] = {"fresh_result_ms": round(min(fresh) * 1e3, 3), "reused_result_ms": round(min(reused) * 1e3, 3),
+            out[f"samples_{n}"] = {"first_call_allocating_ms": round(first * 1e3, 3), "new_array_from_pool_ms": round(min(fresh) * 1e3, 3),
+                                   "reused_result_ms": round(min(reused) * 1e3, 3),
                                    "fields_per_s_fresh": round(n / 3 / min(fresh), 1), "fields_per_s_reused": round(n / 3 / min(reused), 1),
                                    "d2h_GBps_fresh": round(y.nbytes / min(fresh) / 1e9, 2), "d2h_GBps_reused": round(y.nbytes / min(reused) / 1e9, 2)}
             del y, yp
-        out["note"] = ("fresh: predict() returns a new array from the recycling page-locked pool (copy of chunk i overlaps the kernels of chunk "
-                       "i+1); reused: out= a caller-owned pageable array (staged copy, nothing overlaps)")
+        out["note"] = ("first_call_allocating: the pool is empty, the call pays hipHostMalloc; new_array_from_pool (`fresh`): predict() returns a new "
+                       "array over a RECYCLED page-locked buffer (copy of chunk i overlaps the kernels of chunk i+1), min of 3; reused: out= a "
+                       "caller-owned pageable array (staged copy, nothing overlaps)")
         return out
 
 

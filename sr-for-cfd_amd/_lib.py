@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("SRCFD_LIB") or os.path.join(_HERE, "lib", "libsrcfd.s
 OK, ENOENT, EIO, ENOMEM, ENODEV, EINVAL, EKEY, EHIP = 0, -2, -5, -12, -19, -22, -126, -1000
 
 F32, F64, I32, I64, U8, STR, BF16, F16 = 0, 1, 2, 3, 4, 5, 16, 17
-PREC_FP32, PREC_BF16, PREC_FP32_NAIVE, PREC_F16 = 0, 1, 2, 3
+PREC_FP32, PREC_BF16, PREC_FP32_NAIVE, PREC_F16, PREC_FP32X3 = 0, 1, 2, 3, 4
 LAYER_CONV2D, LAYER_CONV2D_TRANSPOSE, LAYER_DENSE, LAYER_FLATTEN, LAYER_RESHAPE = 1, 2, 3, 4, 5
 ACT_LINEAR, ACT_SWISH, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
 FLAG_NAN_GUARD = 1

@@ -90,6 +90,11 @@ struct Model {
   size_t t32_w1 = 0, t32_b1 = 0, t32_w2 = 0, t32_b2 = 0, t32_w3 = 0, t32_b3 = 0, t32_wc = 0;
   int num_cus = 256;
   float* d_pack = nullptr;
+  // SRCFD_PREC_FP32X3: ops the split-bf16 GEMM takes (kernels_x3.hip): x3_off[i] = offset of op i's three weight planes in pack_x3
+  // (elements), or -1.  Built at create, uploaded with the f32 pack.
+  std::vector<int64_t> x3_off;
+  std::vector<uint16_t> pack_x3;
+  uint16_t* d_pack_x3 = nullptr;
 
   float* buf[2] = {nullptr, nullptr};
   int ws_chunk = 0;

@@ -248,6 +248,21 @@ static void plan_tail32(Model& m) {
   m.tail32_op = (int)i;
 }
 
+// SRCFD_PREC_FP32X3: the ops gemm_x3 takes get their weights split into three bf16 planes (kernels_x3.hip).
+static void plan_x3(Model& m) {
+  m.x3_off.assign(m.ops.size(), -1);
+  m.pack_x3.clear();
+  for (size_t i = 0; i < m.ops.size(); ++i) {
+    GemmDesc d = m.ops[i].d;
+    d.M = 0;
+    if (!gemm_x3_qualifies(d)) continue;
+    while (m.pack_x3.size() % 64) m.pack_x3.push_back(0);
+    m.x3_off[i] = (int64_t)m.pack_x3.size();
+    m.pack_x3.resize(m.pack_x3.size() + (size_t)3 * d.N * gemm_x3_kpad(d));
+    gemm_x3_split_weights(d, m.pack.data() + m.ops[i].w_off, m.pack_x3.data() + m.x3_off[i]);
+  }
+}
+
 // enc32 (kernels_enc32.hip): the encoder's four compute layers as one launch.  conv2d_1's weights are re-ordered into
 // v_mfma_f32_16x16x4_f32 A fragments: frag[((w*36 + tap*4 + q)*64 + lane)*4 + j] = W[tap][ci = 16 q + 4 (lane / 16) + j][co = 16 w + lane % 16]
 // (Keras Conv2D kernel (kh, kw, cin, cout)); the other three layers use their ordinary B[K][Npad] operands.
@@ -288,6 +303,7 @@ Model::~Model() {
     (void)hipSetDevice(device);
     free_workspace();
     if (d_pack) (void)hipFree(d_pack);
+    if (d_pack_x3) (void)hipFree(d_pack_x3);
     fused_free(*this);
     drop_graph();
     if (graph_stream) (void)hipStreamDestroy(graph_stream);
@@ -345,6 +361,10 @@ int Model::init_device() {
   { hipDeviceProp_t prop; HIPCHECK(hipGetDeviceProperties(&prop, device)); num_cus = prop.multiProcessorCount; }
   HIPCHECK(hipMalloc(&d_pack, pack.size() * sizeof(float)));
   HIPCHECK(hipMemcpy(d_pack, pack.data(), pack.size() * sizeof(float), hipMemcpyHostToDevice));
+  if (!pack_x3.empty()) {
+    HIPCHECK(hipMalloc(&d_pack_x3, pack_x3.size() * sizeof(uint16_t)));
+    HIPCHECK(hipMemcpy(d_pack_x3, pack_x3.data(), pack_x3.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+  }
   return SRCFD_OK;
 }
 
@@ -428,6 +448,7 @@ int Model::forward_generic(const float* x_dev, int n, const float* aff_in, const
   const int* os = desc.out_shape();
   const int out_elems = os[0] * os[1] * os[2];
   const bool naive = precision == SRCFD_PREC_FP32_NAIVE;
+  const bool x3 = precision == SRCFD_PREC_FP32X3;
   int cur = 0;
   int rc = SRCFD_OK;
   int prev_layer = -1;
@@ -506,6 +527,25 @@ int Model::forward_generic(const float* x_dev, int n, const float* aff_in, const
     }
     size_t j = i + 1;
     while (j < ops.size() && ops[j].layer == op.layer && j - i < 4) ++j;
+    if (x3 && d_pack_x3) {   // SRCFD_PREC_FP32X3: every GEMM of the layer on the split-bf16 kernel (one launch per output phase)
+      bool all = true;
+      for (size_t q = i; q < j && all; ++q) {
+        GemmDesc dq = ops[q].d;
+        dq.M = n * dq.MH * dq.MW;
+        all = x3_off[q] >= 0 && gemm_x3_qualifies(dq);
+      }
+      if (all) {
+        for (size_t q = i; q < j; ++q) {
+          GemmDesc dq = ops[q].d;
+          dq.M = n * dq.MH * dq.MW;
+          const std::string nm = ops[q].name + "(x3)";
+          rc = launch(nm.c_str(), s, [&] { return launch_gemm_x3(dq, X, d_pack_x3 + x3_off[q], d_pack + ops[q].b_off, Y, s); });
+          if (rc) return rc;
+        }
+        i = j - 1;
+        continue;
+      }
+    }
     if (!naive && j - i > 1) {  // the output phases of one transposed convolution: one launch (kernels_fp32.hip, GemmGroup)
       GemmDesc ds[4];
       const float* Bs[4];
@@ -713,6 +753,7 @@ static int finish_create(std::unique_ptr<Model>& m, srcfd_model** out) {
     plan_convt_triple(*m);
     plan_tail32(*m);
     plan_enc32(*m);
+    plan_x3(*m);
   } catch (const std::exception& e) {
     set_error(e.what());
     return SRCFD_EINVAL;
@@ -905,7 +946,7 @@ int64_t srcfd_model_macs_per_sample(const srcfd_model* m) { return m ? M(m)->des
 
 int srcfd_model_set_precision(srcfd_model* m, int precision) {
   return srcfd::abi_guard("srcfd_model_set_precision", [&]() -> int {
-    if (!m || precision < 0 || precision > SRCFD_PREC_F16) { set_error("bad precision"); return SRCFD_EINVAL; }
+    if (!m || precision < 0 || precision > SRCFD_PREC_FP32X3) { set_error("bad precision"); return SRCFD_EINVAL; }
     if ((precision == SRCFD_PREC_BF16 || precision == SRCFD_PREC_F16) && !M(m)->has_fused) {
       set_error("bf16/f16 precision needs the encoder_10+decoder_400 layer graph");
       return SRCFD_EINVAL;
@@ -961,7 +1002,7 @@ int srcfd_model_workspace(srcfd_model* m, int n, size_t* bytes) {
 
 int srcfd_model_footprint(const srcfd_model* m, int n, int precision, size_t bytes[4]) {
   return srcfd::abi_guard("srcfd_model_footprint", [&]() -> int {
-    if (!m || !bytes || n < 0 || precision < 0 || precision > SRCFD_PREC_F16) { set_error("bad arguments"); return SRCFD_EINVAL; }
+    if (!m || !bytes || n < 0 || precision < 0 || precision > SRCFD_PREC_FP32X3) { set_error("bad arguments"); return SRCFD_EINVAL; }
     const srcfd::Model& mm = *M(m);
     const bool lowp = precision == SRCFD_PREC_BF16 || precision == SRCFD_PREC_F16;
     if (lowp && !mm.has_fused) { set_error("bf16/f16 precision needs the encoder_10+decoder_400 layer graph"); return SRCFD_EINVAL; }
@@ -978,7 +1019,7 @@ int srcfd_model_footprint(const srcfd_model* m, int n, int precision, size_t byt
     } else {
       const int chunk = n ? std::min(n, mm.chunk_cap()) : 0;
       bytes[0] = 2 * (size_t)chunk * mm.max_act_elems() * sizeof(float);
-      bytes[1] = params * sizeof(float) * 2;   // packed weights + the per-layer operand orders of the fused f32 kernels (upper bound)
+      bytes[1] = params * sizeof(float) * 2 + mm.pack_x3.size() * sizeof(uint16_t);   // packed weights + the per-layer operand orders of the fused f32 kernels (upper bound) + the split-bf16 planes
     }
     const size_t stage = (size_t)std::min(n, 256);
     bytes[2] = stage * (in_elems + 2 * out_elems + 4) * sizeof(float);   // predict_host: input, two result buffers, affine pairs
@@ -1022,7 +1063,7 @@ int srcfd_model_last_plan(const srcfd_model* m, char* buf, size_t buf_len) {
   return srcfd::abi_guard("srcfd_model_last_plan", [&]() -> int {
     if (!m || !buf || buf_len == 0) { set_error("bad arguments"); return SRCFD_EINVAL; }
     const srcfd::Plan& p = M(m)->plan;
-    const char* prec = p.precision == SRCFD_PREC_BF16 ? "bf16" : p.precision == SRCFD_PREC_F16 ? "f16" : p.precision == SRCFD_PREC_FP32 ? "fp32" : "fp32_naive";
+    const char* prec = p.precision == SRCFD_PREC_BF16 ? "bf16" : p.precision == SRCFD_PREC_F16 ? "f16" : p.precision == SRCFD_PREC_FP32 ? "fp32" : p.precision == SRCFD_PREC_FP32X3 ? "fp32x3" : "fp32_naive";
     char tmp[256];
     if (p.fused)
       snprintf(tmp, sizeof(tmp), "precision=%s encoder=%s dense_1=%s middle=%s tail=%s tail_seg=%d graph=%s", prec, p.sw.enc16 ? "enc16" : "layers",

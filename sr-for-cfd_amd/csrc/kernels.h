@@ -125,6 +125,13 @@ hipError_t launch_tail32(const Tail32Params& p, int num_cus, hipStream_t s);
 int tail32_segments(int n, int H, int num_cus);
 int tail32_blocks(int n, int seg, int num_cus);   // workgroups launch_tail32 starts
 
+// f32-grade GEMM on bf16 MFMAs, operands split exactly into three bf16 terms (kernels_x3.hip; SRCFD_PREC_FP32X3).
+// Wt: [plane 3][N][Kpad] bf16 from gemm_x3_split_weights(); d.M set (the 32-bit input offsets bound the batch).
+bool gemm_x3_qualifies(const GemmDesc& d);
+int gemm_x3_kpad(const GemmDesc& d);
+void gemm_x3_split_weights(const GemmDesc& d, const float* B, uint16_t* out);
+hipError_t launch_gemm_x3(const GemmDesc& d, const float* X, const uint16_t* Wt, const float* bias, float* Y, hipStream_t s);
+
 // Last layer + de-standardise + NaN guard + output cast in one kernel, for the layers gemm_fuses_finalize() accepts.
 bool gemm_fuses_finalize(const GemmDesc& d);
 hipError_t launch_gemm_finalize(const GemmDesc& d, const float* X, const float* B, const float* bias, void* out, int out_dtype,

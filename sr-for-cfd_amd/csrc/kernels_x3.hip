@@ -1,0 +1,246 @@
+// gemm_x3: f32-grade implicit GEMM on the bf16 matrix cores (gfx950 only) -- precision SRCFD_PREC_FP32X3.
+//
+// Why: v_mfma_f32_*_f32 runs at 1/16 of the bf16 MFMA rate on this chip and does not overlap vector work, and the two wide
+// decoder layers (ConvT#0 3x3 s2 256->128 and ConvT#1 2x2 s2 128->64; SURVEY.md 8a rows a13, a14: 45 % of the network's MACs)
+// are pure matrix time: 1.08 ms of the f32 parity path's 3.04 ms per 768 samples.  A float32 value is EXACTLY the sum of three
+// bfloat16 values (8 + 8 + 8 significant bits: hi = top 16 bits, mid = top 16 bits of x - hi, lo = x - hi - mid), so
+//     x w = (xh + xm + xl)(wh + wm + wl) = xh wh + xh wm + xm wh + xh wl + xl wh + xm wm  + terms below 2^-24 |x w|
+// six bf16 MFMAs with f32 accumulation instead of one f32 MFMA: 6/16 of the matrix time, and products that are exact in
+// f32 before they are summed.  Measured on the CPU emulation (tests/split_precision_study.py, profiles/r04/n_...): 3e-7
+// relative L2 on the whole network against float64 -- tighter than plain f32 accumulation (5e-7) -- where two terms
+// (3 MFMAs) give 1.3e-5 and miss the 1e-5 bar.
+//
+// Structure: activations stay float32 in HBM (the neighbours -- dense_skinny32 in front, tail32 behind -- are f32 kernels) and are
+// split in registers (truncation split: two ANDs and two exact subtractions per element; the packs take the high halves);
+// weights are split on the host ([plane][n][Kpad] bf16) and are the only operand that goes through LDS.  See the kernel.
+// Epilogue: bias + swish in f32, rows leave as whole 128-byte lines through a wave-private LDS image.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <cstring>
+
+#include "dev16.h"
+#include "kernels.h"
+#include "kernels16.h"   // lds_attr_once
+
+namespace srcfd {
+
+constexpr int X3_BP = 128, X3_BN = 128, X3_BK = 32, X3_PITCH = 40;     // weight rows in LDS: 32 k + 8 pad = 80 B (5 x 16 B: conflict-free b128 reads)
+constexpr int X3_PLANE = X3_BN * X3_PITCH;                              // elements per weight plane
+constexpr int X3_BUF = 3 * X3_PLANE;                                    // one stage: three planes
+constexpr int X3_LDS = 2 * X3_BUF * 2;                                  // two stages: 61 440 B -> two workgroups per CU
+constexpr int X3_EP = 36;                                               // epilogue image pitch (floats): 32 channels + 4
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vectors: arrays of HIP's uint4 (a struct) end up in scratch
+__device__ __forceinline__ f32x16 mfma_bf(const u32x4& a, const u32x4& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(s16x8, a), __builtin_bit_cast(s16x8, b), c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float swish_f32(float z) { return z * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.4426950408889634f)); }
+
+// x = hi + mid + lo exactly: hi / mid are x / the first remainder with their low 16 bits cleared, lo is the second remainder (at
+// most 8 significant bits are left in it).  Eight consecutive k values of one pixel -> one MFMA B fragment per plane; the packs
+// take the HIGH halves (v_perm_b32), which for lo is the same truncation.
+__device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, u32x4& fh, u32x4& fm, u32x4& fl) {
+  uint32_t hm[8], mm[8], lm[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float x = i < 4 ? v0[i & 3] : v1[i & 3];
+    hm[i] = __builtin_bit_cast(uint32_t, x) & 0xffff0000u;
+    const float r1 = x - __builtin_bit_cast(float, hm[i]);
+    mm[i] = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
+    lm[i] = __builtin_bit_cast(uint32_t, r1 - __builtin_bit_cast(float, mm[i]));
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    fh[q] = __builtin_amdgcn_perm(hm[2 * q + 1], hm[2 * q], 0x07060302u);
+    fm[q] = __builtin_amdgcn_perm(mm[2 * q + 1], mm[2 * q], 0x07060302u);
+    fl[q] = __builtin_amdgcn_perm(lm[2 * q + 1], lm[2 * q], 0x07060302u);
+  }
+}
+
+// Workgroup tile 128 pixels x 128 channels, four waves of 32 pixels x 128 channels.  The pixel operand never touches LDS: a lane
+// of the 32x32x16 MFMA holds 8 consecutive k of ONE pixel, which is 32 contiguous bytes of that pixel's f32 row -- loaded one
+// k-tile ahead straight into registers and split there (every pixel is split exactly once).  Only the weights (shared by the four
+// waves) go through LDS: three planes, two stages, ONE barrier per k-tile.
+// Two accumulator sets: the MFMA adder aligns its 16 products and the accumulator to the largest exponent and TRUNCATES what
+// falls below (tools/microbench11.hip) -- products 2^-8 and 2^-16 below the hi x hi ones lose their low bits against a running
+// hi x hi sum, with a bias (measured 3e-5 on a layer, where the arithmetic itself is good to 1.5e-7).  So the hi x hi products
+// accumulate alone and the five small products in a set of their own (2^-8 terms last); the two sets meet in one f32 add.
+__global__ void __launch_bounds__(256, 2) gemm_x3(GemmDesc d, const float* __restrict__ X, const uint16_t* __restrict__ Wt, int Kpad, int64_t wplane,
+                                                   const float* __restrict__ bias, float* __restrict__ Y) {
+  extern __shared__ __attribute__((aligned(16))) char gsm[];
+  uint16_t* Ws = reinterpret_cast<uint16_t*>(gsm);                 // [stage 2][plane 3][X3_BN][X3_PITCH]
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.x * X3_BP, n0 = blockIdx.y * X3_BN;
+
+  // this lane's pixel (row of the implicit GEMM)
+  const int m = m0 + wave * 32 + l31;
+  int img = -1, my = 0, mx = 0;
+  if (m < d.M) {
+    const int per = d.MH * d.MW;
+    img = m / per;
+    const int r = m - img * per;
+    my = r / d.MW;
+    mx = r - my * d.MW;
+  }
+  const bool check = d.TY * d.TX > 1 || d.cy != 0 || d.cx != 0;   // taps that can leave the image
+  const int by0 = my * d.ay + d.cy, bx0 = mx * d.ax + d.cx;
+  const int xy = img >= 0 ? by0 : -(1 << 28);                      // rows past M never pass the bounds test
+  int xoff = ((img * d.IH + by0) * d.IW + bx0) * d.CI + 8 * h;
+  if (!check && img < 0) xoff = 8 * h;                             // k == s layers: read row 0, the result is discarded
+  // weight staging: rows (tid >> 2) and + 64, 16-byte chunk tid & 3 of the k-tile, per plane
+  const int wrow = tid >> 2, c8 = tid & 3;
+  const int woff0 = (n0 + wrow) * Kpad + c8 * 8, woff1 = (n0 + wrow + 64) * Kpad + c8 * 8;
+  const int wlds = wrow * X3_PITCH + c8 * 8;
+
+  f32x4 xr[4];        // the k-tile's 32 k of this lane's pixel that its half h needs: k = 16 kk + 8 h + 0..7, kk = 0, 1
+  u32x4 wr[3][2];
+  auto g2r = [&](int k0) {
+    const int tap = k0 / d.CI, ci0 = k0 - tap * d.CI;
+    const int ty = tap / d.TX, tx = tap - ty * d.TX;
+    const int dy = ty * d.by, dx = tx * d.bx;
+    const bool ok = !check || ((unsigned)(xy + dy) < (unsigned)d.IH && (unsigned)(bx0 + dx) < (unsigned)d.IW);
+    const float* src = X + (xoff + (dy * d.IW + dx) * d.CI + ci0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *reinterpret_cast<const f32x4*>(src + 16 * (q >> 1) + 4 * (q & 1));
+      xr[q] = v;
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      wr[p][0] = *reinterpret_cast<const u32x4*>(Wt + (p * wplane + woff0 + k0));
+      wr[p][1] = *reinterpret_cast<const u32x4*>(Wt + (p * wplane + woff1 + k0));
+    }
+  };
+  auto w2l = [&](int stage) {
+    uint16_t* dst = Ws + stage * X3_BUF + wlds;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      *reinterpret_cast<u32x4*>(dst + p * X3_PLANE) = wr[p][0];
+      *reinterpret_cast<u32x4*>(dst + p * X3_PLANE + 64 * X3_PITCH) = wr[p][1];
+    }
+  };
+
+  f32x16 accH[4], accR[4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { accH[a][r] = 0.f; accR[a][r] = 0.f; }
+
+  g2r(0);
+  w2l(0);
+  u32x4 bh[2], bm[2], bl[2];
+  split8(xr[0], xr[1], bh[0], bm[0], bl[0]);
+  split8(xr[2], xr[3], bh[1], bm[1], bl[1]);
+  __syncthreads();
+  const uint16_t* wsr = Ws + l31 * X3_PITCH + h * 8;
+  int stage = 0;
+  for (int k0 = 0; k0 < d.K; k0 += X3_BK) {
+    const bool more = k0 + X3_BK < d.K;
+    if (more) g2r(k0 + X3_BK);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const uint16_t* wp = wsr + stage * X3_BUF + a * 32 * X3_PITCH + kk * 16;
+        const u32x4 ah = *reinterpret_cast<const u32x4*>(wp), am = *reinterpret_cast<const u32x4*>(wp + X3_PLANE),
+                    al = *reinterpret_cast<const u32x4*>(wp + 2 * X3_PLANE);
+        f32x16 c = accR[a];
+        c = mfma_bf(am, bm[kk], c);
+        c = mfma_bf(ah, bl[kk], c);
+        c = mfma_bf(al, bh[kk], c);
+        c = mfma_bf(ah, bm[kk], c);
+        c = mfma_bf(am, bh[kk], c);
+        accR[a] = c;
+        accH[a] = mfma_bf(ah, bh[kk], accH[a]);
+      }
+    }
+    if (more) {
+      w2l(stage ^ 1);    // the other stage was last read before the previous barrier
+      split8(xr[0], xr[1], bh[0], bm[0], bl[0]);
+      split8(xr[2], xr[3], bh[1], bm[1], bl[1]);
+    }
+    __syncthreads();
+    stage ^= 1;
+  }
+
+  // epilogue: the two sets meet, bias + activation in f32; a lane owns one pixel and 4 consecutive channels per register quad.
+  // Each 32 x 32 sub-tile goes through the wave's LDS image and leaves as 32 rows of 128 contiguous bytes.
+  float* image = reinterpret_cast<float*>(gsm) + wave * (32 * X3_EP);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int nb = n0 + a * 32;   // wave-uniform
+    if (nb >= d.N) continue;
+    const float* bp = bias + nb + 4 * h;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 bv = *reinterpret_cast<const float4*>(bp + 8 * q);
+      f32x4 v = {accH[a][4 * q] + accR[a][4 * q] + bv.x, accH[a][4 * q + 1] + accR[a][4 * q + 1] + bv.y, accH[a][4 * q + 2] + accR[a][4 * q + 2] + bv.z,
+                 accH[a][4 * q + 3] + accR[a][4 * q + 3] + bv.w};
+      if (d.act == SRCFD_ACT_SWISH) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = swish_f32(v[i]);
+      }
+      *reinterpret_cast<f32x4*>(image + l31 * X3_EP + 8 * q + 4 * h) = v;
+    }
+    const int ph = nb / d.CO, co = nb - ph * d.CO, py = ph / d.nphx, px = ph - py * d.nphx;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int r = (lane >> 3) + 8 * it, c = lane & 7;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(image + r * X3_EP + 4 * c);
+      // the pixel of row r: lane r of this wave holds its (img, my, mx)
+      const int im = __shfl(img, r, 64), ry = __shfl(my, r, 64), rx = __shfl(mx, r, 64);
+      if (im >= 0) {
+        const int64_t off = (((int64_t)im * d.OH + ry * d.os + d.oy0 + py) * d.OW + rx * d.os + d.ox0 + px) * d.OC + co + 4 * c;
+        *reinterpret_cast<f32x4*>(Y + off) = v;
+      }
+    }
+  }
+}
+
+// Qualifies: a GEMM the generic f32 kernel would run, with whole 32-deep k-tiles inside a tap and whole 128-channel blocks,
+// channel groups of 32 inside one output phase, 16-byte aligned rows on both sides, swish or linear.
+bool gemm_x3_qualifies(const GemmDesc& d) {
+  return d.K >= 128 && d.CI % X3_BK == 0 && d.N % X3_BN == 0 && d.CO % 32 == 0 && d.OC % 4 == 0 && (d.act == SRCFD_ACT_SWISH || d.act == SRCFD_ACT_LINEAR) &&
+         (d.M <= 0 || (int64_t)(d.M / (d.MH * d.MW) + 1) * d.IH * d.IW * d.CI < (1ll << 31));   // 32-bit element offsets into X
+}
+
+int gemm_x3_kpad(const GemmDesc& d) { return (d.K + X3_BK - 1) / X3_BK * X3_BK; }
+
+// B[K][Npad] f32 (the f32 engine's operand) -> Wt[plane 3][N][Kpad] bf16, exact three-way split by truncation
+void gemm_x3_split_weights(const GemmDesc& d, const float* B, uint16_t* out) {
+  const int Kpad = gemm_x3_kpad(d);
+  const size_t plane = (size_t)d.N * Kpad;
+  std::memset(out, 0, 3 * plane * sizeof(uint16_t));
+  for (int k = 0; k < d.K; ++k)
+    for (int n = 0; n < d.N; ++n) {
+      const float w = B[(size_t)k * d.Npad + n];
+      uint32_t b0, b1, b2;
+      std::memcpy(&b0, &w, 4);
+      b0 &= 0xffff0000u;
+      float hi; std::memcpy(&hi, &b0, 4);
+      const float r1 = w - hi;
+      std::memcpy(&b1, &r1, 4);
+      b1 &= 0xffff0000u;
+      float mid; std::memcpy(&mid, &b1, 4);
+      const float r2 = r1 - mid;
+      std::memcpy(&b2, &r2, 4);
+      const size_t o = (size_t)n * Kpad + k;
+      out[o] = (uint16_t)(b0 >> 16); out[plane + o] = (uint16_t)(b1 >> 16); out[2 * plane + o] = (uint16_t)(b2 >> 16);
+    }
+}
+
+hipError_t launch_gemm_x3(const GemmDesc& d, const float* X, const uint16_t* Wt, const float* bias, float* Y, hipStream_t s) {
+  if (d.M <= 0) return hipSuccess;
+  hipError_t e = lds_attr_once(reinterpret_cast<const void*>(gemm_x3), X3_LDS);
+  if (e != hipSuccess) return e;
+  const int Kpad = gemm_x3_kpad(d);
+  dim3 grid((unsigned)((d.M + X3_BP - 1) / X3_BP), (unsigned)(d.N / X3_BN));
+  hipLaunchKernelGGL(gemm_x3, grid, dim3(256), X3_LDS, s, d, X, Wt, Kpad, (int64_t)d.N * Kpad, bias, Y);
+  return hipGetLastError();
+}
+
+}  // namespace srcfd

@@ -16,7 +16,8 @@ import numpy as np
 from . import _lib as L
 
 PRECISIONS = {"fp32": L.PREC_FP32, "float32": L.PREC_FP32, "bf16": L.PREC_BF16, "bfloat16": L.PREC_BF16,
-              "fp32_naive": L.PREC_FP32_NAIVE, "f16": L.PREC_F16, "fp16": L.PREC_F16, "float16": L.PREC_F16}
+              "fp32_naive": L.PREC_FP32_NAIVE, "f16": L.PREC_F16, "fp16": L.PREC_F16, "float16": L.PREC_F16,
+              "fp32x3": L.PREC_FP32X3}   # f32-grade: the wide decoder GEMMs as six bf16 MFMAs on exactly split operands (csrc/kernels_x3.hip)
 _ACT = {"linear": L.ACT_LINEAR, None: L.ACT_LINEAR, "swish": L.ACT_SWISH, "silu": L.ACT_SWISH, "relu": L.ACT_RELU,
         "sigmoid": L.ACT_SIGMOID, "tanh": L.ACT_TANH}
 _KIND = {"conv2d": L.LAYER_CONV2D, "conv2d_transpose": L.LAYER_CONV2D_TRANSPOSE, "dense": L.LAYER_DENSE,
@@ -248,7 +249,7 @@ class SRModel:
     @property
     def precision(self) -> str:
         p = L.lib.srcfd_model_get_precision(self._h)
-        return {L.PREC_FP32: "fp32", L.PREC_BF16: "bf16", L.PREC_FP32_NAIVE: "fp32_naive", L.PREC_F16: "f16"}[p]
+        return {L.PREC_FP32: "fp32", L.PREC_BF16: "bf16", L.PREC_FP32_NAIVE: "fp32_naive", L.PREC_F16: "f16", L.PREC_FP32X3: "fp32x3"}[p]
 
     @precision.setter
     def precision(self, name: str):
