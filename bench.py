@@ -22,6 +22,8 @@ Prints ONE JSON line (rank 0).  Besides the contract's keys it carries
   cpu_baseline  torch-CPU (oneDNN) restatement timed on the host cores (N = 1)
   parity_path   the same batch through the f32 kernels (the <= 1e-5 path):
                 fields/s, ms/step, its own roofline, rel-L2 vs the f64 oracle
+  parity_path_x3  the same at SRCFD_PREC_FP32X3 (f32-grade: the two wide decoder
+                layers as six bf16 MFMAs on exactly split operands), same fields
   train         BASELINE config 4: conv-AE training step, micro-batch 8 per
                 GPU, flat-gradient all-reduce (RCCL) + Adam, samples/s
   tiled         BASELINE config 5: 40x40x3 -> 1600x1600x3 through 4x4 tiles, f16
@@ -718,7 +720,7 @@ def main():
         return
 
     y_gpu = {}
-    parity = train = tiled = host_io = None
+    parity = parity_x3 = train = tiled = host_io = None
     extra_errors = {}
 
     def leg(name, fn):
@@ -748,6 +750,15 @@ def main():
                 y_gpu["fp32"] = y_par[:8].cpu().numpy()
             return rec
         parity = leg("parity_path", _parity)
+
+        def _parity_x3():   # the same batch at SRCFD_PREC_FP32X3: f32-grade, ConvT#0 / ConvT#1 as six bf16 MFMAs on exactly split operands
+            rec, y_par = job.run_sr("fp32x3", "f32", max(5, min(args.steps, 20)), min(args.warmup, 3))
+            if job.rank == 0 and not args.no_cpu_baseline:
+                y_gpu["fp32x3"] = y_par[:8].cpu().numpy()
+            rec["roofline"]["note"] = ("algorithmic f32 FLOPs over the f32 MFMA peak, as for parity_path -- but ConvT#0 / ConvT#1 (45 % of the MACs) run as 6 bf16 "
+                                       "MFMAs per f32 product (kernels_x3.hip), the rest on the f32 kernels: a mixed-pipe number, for comparison with parity_path only")
+            return rec
+        parity_x3 = leg("parity_path_x3", _parity_x3)
 
     pci = None
     try:
@@ -779,9 +790,10 @@ def main():
         if not args.no_cpu_baseline:
             try:
                 cpu = cpu_baseline(job.x_h, job.ain_h, job.aout_h, job.enc_w, job.dec_w, y_gpu)
-                if parity is not None and "fp32" in cpu["gpu_rel_l2_vs_f64_oracle"]:
-                    parity["rel_l2_vs_f64_oracle"] = cpu["gpu_rel_l2_vs_f64_oracle"]["fp32"]
-                    parity["tolerance"] = 1e-5
+                for rec_, key_ in ((parity, "fp32"), (parity_x3, "fp32x3")):
+                    if rec_ is not None and key_ in cpu["gpu_rel_l2_vs_f64_oracle"]:
+                        rec_["rel_l2_vs_f64_oracle"] = cpu["gpu_rel_l2_vs_f64_oracle"][key_]
+                        rec_["tolerance"] = 1e-5
             except Exception as e:   # noqa: BLE001
                 extra_errors["cpu_baseline"] = f"{type(e).__name__}: {e}"[:300]
     job.barrier()
@@ -801,7 +813,7 @@ def main():
             "kernels_ms": head.get("kernels_ms"), "kernels_ms_sum": head.get("kernels_ms_sum"), "launch_gap_ms": head.get("launch_gap_ms"),
             "roofline": head.get("roofline"), "last_plan": head.get("last_plan"),
             "cpu_baseline": cpu,
-            "parity_path": parity, "train": train, "tiled": tiled, "host_io": host_io,
+            "parity_path": parity, "parity_path_x3": parity_x3, "train": train, "tiled": tiled, "host_io": host_io,
             "ms_per_step_rank_min_max": head.get("ms_per_step_rank_min_max"), "untimed_pre_warm_ms": head.get("untimed_pre_warm_ms"),
             "env": dict(env, gpu_state_before_headline=gpu_before, gpu_state_after_headline=gpu_after),
         }

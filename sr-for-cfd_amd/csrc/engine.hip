@@ -527,7 +527,10 @@ int Model::forward_generic(const float* x_dev, int n, const float* aff_in, const
     }
     size_t j = i + 1;
     while (j < ops.size() && ops[j].layer == op.layer && j - i < 4) ++j;
-    if (x3 && d_pack_x3) {   // SRCFD_PREC_FP32X3: every GEMM of the layer on the split-bf16 kernel (one launch per output phase)
+    // SRCFD_PREC_FP32X3: every GEMM of the layer on the split-bf16 kernel (one launch per output phase) -- from 64 samples on: below
+    // that its serial k loops lose to the generic f32 kernels' split-K launches (tools/precision_sweep.py: 0.26 vs 0.13 ms at 3
+    // samples, break-even between 48 and 96), so small calls run exactly the SRCFD_PREC_FP32 path.
+    if (x3 && d_pack_x3 && n >= 64) {
       bool all = true;
       for (size_t q = i; q < j && all; ++q) {
         GemmDesc dq = ops[q].d;
@@ -539,7 +542,7 @@ int Model::forward_generic(const float* x_dev, int n, const float* aff_in, const
           GemmDesc dq = ops[q].d;
           dq.M = n * dq.MH * dq.MW;
           const std::string nm = ops[q].name + "(x3)";
-          rc = launch(nm.c_str(), s, [&] { return launch_gemm_x3(dq, X, d_pack_x3 + x3_off[q], d_pack + ops[q].b_off, Y, s); });
+          rc = launch(nm.c_str(), s, [&] { return launch_gemm_x3(dq, X, d_pack_x3 + x3_off[q], d_pack + ops[q].b_off, Y, s, num_cus); });
           if (rc) return rc;
         }
         i = j - 1;

@@ -130,7 +130,7 @@ int tail32_blocks(int n, int seg, int num_cus);   // workgroups launch_tail32 st
 bool gemm_x3_qualifies(const GemmDesc& d);
 int gemm_x3_kpad(const GemmDesc& d);
 void gemm_x3_split_weights(const GemmDesc& d, const float* B, uint16_t* out);
-hipError_t launch_gemm_x3(const GemmDesc& d, const float* X, const uint16_t* Wt, const float* bias, float* Y, hipStream_t s);
+hipError_t launch_gemm_x3(const GemmDesc& d, const float* X, const uint16_t* Wt, const float* bias, float* Y, hipStream_t s, int num_cus = 256);
 
 // Last layer + de-standardise + NaN guard + output cast in one kernel, for the layers gemm_fuses_finalize() accepts.
 bool gemm_fuses_finalize(const GemmDesc& d);

@@ -17,6 +17,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <cstring>
 
 #include "dev16.h"
@@ -28,8 +29,9 @@ namespace srcfd {
 constexpr int X3_BP = 128, X3_BN = 128, X3_BK = 32, X3_PITCH = 40;     // weight rows in LDS: 32 k + 8 pad = 80 B (5 x 16 B: conflict-free b128 reads)
 constexpr int X3_PLANE = X3_BN * X3_PITCH;                              // elements per weight plane
 constexpr int X3_BUF = 3 * X3_PLANE;                                    // one stage: three planes
-constexpr int X3_LDS = 2 * X3_BUF * 2;                                  // two stages: 61 440 B -> two workgroups per CU
-constexpr int X3_EP = 36;                                               // epilogue image pitch (floats): 32 channels + 4
+constexpr int X3_WLDS = 2 * X3_BUF * 2;                                 // two stages: 61 440 B
+constexpr int X3_EP = 36;                                               // wave image pitch (floats): 32 + 4 (144 B = 9 x 16 B: conflict-free)
+constexpr int X3_LDS = X3_WLDS + 4 * 32 * X3_EP * 4;                    // + one image per wave: 79 872 B -> two workgroups per CU
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // native vectors: arrays of HIP's uint4 (a struct) end up in scratch
 __device__ __forceinline__ f32x16 mfma_bf(const u32x4& a, const u32x4& b, const f32x16& c) {
@@ -59,14 +61,61 @@ __device__ __forceinline__ void split8(const f32x4& v0, const f32x4& v1, u32x4& 
   }
 }
 
-// Workgroup tile 128 pixels x 128 channels, four waves of 32 pixels x 128 channels.  The pixel operand never touches LDS: a lane
-// of the 32x32x16 MFMA holds 8 consecutive k of ONE pixel, which is 32 contiguous bytes of that pixel's f32 row -- loaded one
-// k-tile ahead straight into registers and split there (every pixel is split exactly once).  Only the weights (shared by the four
-// waves) go through LDS: three planes, two stages, ONE barrier per k-tile.
-// Two accumulator sets: the MFMA adder aligns its 16 products and the accumulator to the largest exponent and TRUNCATES what
-// falls below (tools/microbench11.hip) -- products 2^-8 and 2^-16 below the hi x hi ones lose their low bits against a running
-// hi x hi sum, with a bias (measured 3e-5 on a layer, where the arithmetic itself is good to 1.5e-7).  So the hi x hi products
-// accumulate alone and the five small products in a set of their own (2^-8 terms last); the two sets meet in one f32 add.
+// Epilogue of one wave's 32 pixels x 128 channels: the two accumulator sets meet, bias + activation in f32.  A lane owns one pixel
+// and 4 consecutive channels per register quad; each 32 x 32 sub-tile goes through the wave's LDS image and leaves as 32 rows of
+// 128 contiguous bytes.  orow[it]: output element offset of pixel (lane >> 3) + 8 it without the phase / channel part, -1 = no pixel.
+__device__ __forceinline__ void x3_epilogue(const GemmDesc& d, const f32x16 (&accH)[4], const f32x16 (&accR)[4], const float* __restrict__ bias,
+                                            float* __restrict__ Y, float* image, const int n0, const int lane, const int (&orow)[4]) {
+  const int h = lane >> 5, l31 = lane & 31;
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    const int nb = n0 + a * 32;   // wave-uniform
+    if (nb >= d.N) continue;
+    const float* bp = bias + nb + 4 * h;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 bv = *reinterpret_cast<const float4*>(bp + 8 * q);
+      f32x4 v = {accH[a][4 * q] + accR[a][4 * q] + bv.x, accH[a][4 * q + 1] + accR[a][4 * q + 1] + bv.y, accH[a][4 * q + 2] + accR[a][4 * q + 2] + bv.z,
+                 accH[a][4 * q + 3] + accR[a][4 * q + 3] + bv.w};
+      if (d.act == SRCFD_ACT_SWISH) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = swish_f32(v[i]);
+      }
+      *reinterpret_cast<f32x4*>(image + l31 * X3_EP + 8 * q + 4 * h) = v;
+    }
+    const int ph = nb / d.CO, co = nb - ph * d.CO, py = ph / d.nphx, px = ph - py * d.nphx;
+    const int poff = (py * d.OW + px) * d.OC + co + 4 * (lane & 7);
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(image + ((lane >> 3) + 8 * it) * X3_EP + 4 * (lane & 7));
+      if (orow[it] >= 0) *reinterpret_cast<f32x4*>(Y + (orow[it] + poff)) = v;
+    }
+  }
+}
+
+// A wave's 32 pixels x 32 k of one k-tile come from HBM as whole 128-byte row segments (lane -> pixel (lane >> 3) + 8 j, 16-byte chunk
+// lane & 7: 8 rows per instruction), are parked in the wave's LDS image (the epilogue's: 32 rows of 36 floats) and read back in
+// MFMA fragment shape (lane -> pixel lane & 31, 8 consecutive k).  Loading the fragment shape straight from HBM (32 rows x two
+// 16-byte pieces per instruction) thrashed L1 -- eight waves x 16 KB of row pieces per CU -- and ran 10 % slower.
+__device__ __forceinline__ void x3_park_and_split(float* image, const int lane, const f32x4 (&xr)[4], u32x4 (&bh)[2], u32x4 (&bm)[2], u32x4 (&bl)[2]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(image + ((lane >> 3) + 8 * j) * X3_EP + 4 * (lane & 7)) = xr[j];
+  const float* src = image + (lane & 31) * X3_EP + 8 * (lane >> 5);
+#pragma unroll
+  for (int kk = 0; kk < 2; ++kk) {
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(src + 16 * kk), v1 = *reinterpret_cast<const f32x4*>(src + 16 * kk + 4);
+    split8(v0, v1, bh[kk], bm[kk], bl[kk]);
+  }
+}
+
+// Workgroup tile 128 pixels x 128 channels, four waves of 32 pixels x 128 channels.  A wave stages and splits its own pixels (loaded
+// one k-tile ahead, parked in a wave-private LDS image, split in registers: every pixel is split exactly once, no barrier involved);
+// only the weights are shared by the four waves: three planes, two LDS stages, ONE barrier per k-tile.
+// Two accumulator sets: products 2^-8 and 2^-16 below the hi x hi ones lose their low bits when they are added to a running
+// hi x hi sum -- each of an MFMA's 16 products is cut at the accumulator's last bit on the way into the adder, not the sum once
+// (tools/microbench11.hip mode 3, profiles/r04/o_...: 2.5e-4 of the small plane's sum against 6e-7 in an accumulator of its own).
+// With all six products in one accumulator a layer came out at 3e-5 where the arithmetic is good to 1.5e-7.  So the hi x hi
+// products accumulate alone and the five small products in a set of their own (2^-8 terms last); the sets meet in one f32 add.
 __global__ void __launch_bounds__(256, 2) gemm_x3(GemmDesc d, const float* __restrict__ X, const uint16_t* __restrict__ Wt, int Kpad, int64_t wplane,
                                                    const float* __restrict__ bias, float* __restrict__ Y) {
   extern __shared__ __attribute__((aligned(16))) char gsm[];
@@ -75,7 +124,7 @@ __global__ void __launch_bounds__(256, 2) gemm_x3(GemmDesc d, const float* __res
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m0 = blockIdx.x * X3_BP, n0 = blockIdx.y * X3_BN;
 
-  // this lane's pixel (row of the implicit GEMM)
+  // lane l31 of either half decodes pixel l31 of the wave's tile; the lanes that load / store a row fetch its numbers by shuffle
   const int m = m0 + wave * 32 + l31;
   int img = -1, my = 0, mx = 0;
   if (m < d.M) {
@@ -87,27 +136,37 @@ __global__ void __launch_bounds__(256, 2) gemm_x3(GemmDesc d, const float* __res
   }
   const bool check = d.TY * d.TX > 1 || d.cy != 0 || d.cx != 0;   // taps that can leave the image
   const int by0 = my * d.ay + d.cy, bx0 = mx * d.ax + d.cx;
-  const int xy = img >= 0 ? by0 : -(1 << 28);                      // rows past M never pass the bounds test
-  int xoff = ((img * d.IH + by0) * d.IW + bx0) * d.CI + 8 * h;
-  if (!check && img < 0) xoff = 8 * h;                             // k == s layers: read row 0, the result is discarded
+  const int xy_own = img >= 0 ? by0 : -(1 << 28);                  // rows past M never pass the bounds test
+  int xoff_own = ((img * d.IH + by0) * d.IW + bx0) * d.CI;
+  if (!check && img < 0) xoff_own = 0;                             // k == s layers: read row 0, nothing is stored
+  const int o_own = img >= 0 ? ((img * d.OH + my * d.os + d.oy0) * d.OW + mx * d.os + d.ox0) * d.OC : -1;   // 32-bit: gemm_x3_qualifies bounds the batch
+  int xo[4], xy[4], xx[4], orow[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = (lane >> 3) + 8 * j;
+    xo[j] = __shfl(xoff_own, r, 64) + 4 * (lane & 7);
+    xy[j] = __shfl(xy_own, r, 64);
+    xx[j] = __shfl(bx0, r, 64);
+    orow[j] = __shfl(o_own, r, 64);
+  }
   // weight staging: rows (tid >> 2) and + 64, 16-byte chunk tid & 3 of the k-tile, per plane
   const int wrow = tid >> 2, c8 = tid & 3;
   const int woff0 = (n0 + wrow) * Kpad + c8 * 8, woff1 = (n0 + wrow + 64) * Kpad + c8 * 8;
   const int wlds = wrow * X3_PITCH + c8 * 8;
+  float* image = reinterpret_cast<float*>(gsm + X3_WLDS) + wave * (32 * X3_EP);
 
-  f32x4 xr[4];        // the k-tile's 32 k of this lane's pixel that its half h needs: k = 16 kk + 8 h + 0..7, kk = 0, 1
+  f32x4 xr[4];
   u32x4 wr[3][2];
   auto g2r = [&](int k0) {
     const int tap = k0 / d.CI, ci0 = k0 - tap * d.CI;
     const int ty = tap / d.TX, tx = tap - ty * d.TX;
     const int dy = ty * d.by, dx = tx * d.bx;
-    const bool ok = !check || ((unsigned)(xy + dy) < (unsigned)d.IH && (unsigned)(bx0 + dx) < (unsigned)d.IW);
-    const float* src = X + (xoff + (dy * d.IW + dx) * d.CI + ci0);
+    const int toff = (dy * d.IW + dx) * d.CI + ci0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int j = 0; j < 4; ++j) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) v = *reinterpret_cast<const f32x4*>(src + 16 * (q >> 1) + 4 * (q & 1));
-      xr[q] = v;
+      if (!check || ((unsigned)(xy[j] + dy) < (unsigned)d.IH && (unsigned)(xx[j] + dx) < (unsigned)d.IW)) v = *reinterpret_cast<const f32x4*>(X + (xo[j] + toff));
+      xr[j] = v;
     }
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
@@ -133,8 +192,7 @@ __global__ void __launch_bounds__(256, 2) gemm_x3(GemmDesc d, const float* __res
   g2r(0);
   w2l(0);
   u32x4 bh[2], bm[2], bl[2];
-  split8(xr[0], xr[1], bh[0], bm[0], bl[0]);
-  split8(xr[2], xr[3], bh[1], bm[1], bl[1]);
+  x3_park_and_split(image, lane, xr, bh, bm, bl);
   __syncthreads();
   const uint16_t* wsr = Ws + l31 * X3_PITCH + h * 8;
   int stage = 0;
@@ -160,52 +218,114 @@ __global__ void __launch_bounds__(256, 2) gemm_x3(GemmDesc d, const float* __res
     }
     if (more) {
       w2l(stage ^ 1);    // the other stage was last read before the previous barrier
-      split8(xr[0], xr[1], bh[0], bm[0], bl[0]);
-      split8(xr[2], xr[3], bh[1], bm[1], bl[1]);
+      x3_park_and_split(image, lane, xr, bh, bm, bl);
     }
     __syncthreads();
     stage ^= 1;
   }
+  x3_epilogue(d, accH, accR, bias, Y, image, n0, lane, orow);
+}
 
-  // epilogue: the two sets meet, bias + activation in f32; a lane owns one pixel and 4 consecutive channels per register quad.
-  // Each 32 x 32 sub-tile goes through the wave's LDS image and leaves as 32 rows of 128 contiguous bytes.
-  float* image = reinterpret_cast<float*>(gsm) + wave * (32 * X3_EP);
-#pragma unroll
-  for (int a = 0; a < 4; ++a) {
-    const int nb = n0 + a * 32;   // wave-uniform
-    if (nb >= d.N) continue;
-    const float* bp = bias + nb + 4 * h;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 bv = *reinterpret_cast<const float4*>(bp + 8 * q);
-      f32x4 v = {accH[a][4 * q] + accR[a][4 * q] + bv.x, accH[a][4 * q + 1] + accR[a][4 * q + 1] + bv.y, accH[a][4 * q + 2] + accR[a][4 * q + 2] + bv.z,
-                 accH[a][4 * q + 3] + accR[a][4 * q + 3] + bv.w};
-      if (d.act == SRCFD_ACT_SWISH) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = swish_f32(v[i]);
-      }
-      *reinterpret_cast<f32x4*>(image + l31 * X3_EP + 8 * q + 4 * h) = v;
-    }
-    const int ph = nb / d.CO, co = nb - ph * d.CO, py = ph / d.nphx, px = ph - py * d.nphx;
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-      const int r = (lane >> 3) + 8 * it, c = lane & 7;
-      const f32x4 v = *reinterpret_cast<const f32x4*>(image + r * X3_EP + 4 * c);
-      // the pixel of row r: lane r of this wave holds its (img, my, mx)
-      const int im = __shfl(img, r, 64), ry = __shfl(my, r, 64), rx = __shfl(mx, r, 64);
-      if (im >= 0) {
-        const int64_t off = (((int64_t)im * d.OH + ry * d.os + d.oy0 + py) * d.OW + rx * d.os + d.ox0 + px) * d.OC + co + 4 * c;
-        *reinterpret_cast<f32x4*>(Y + off) = v;
-      }
-    }
+// Short-K layers without taps (ConvT#1: K = 128, kernel == stride, 492 MB of f32 output per 768 samples): the k loop is four tiles
+// long, so in gemm_x3 a workgroup is mostly prologue (first loads at full latency) and epilogue (64 KB of stores), with two
+// workgroups per CU to hide them behind.  Here the three weight planes of a 128-channel block stay in LDS for the whole kernel
+// (3 x 128 x K bf16 = 96 KB), loaded once; eight waves per CU each walk their own 32-pixel tiles with NO barrier after that, the
+// next tile's first operands in flight under the current tile's epilogue, so the waves drift apart and one wave's stores and
+// loads sit under the others' MFMAs.
+constexpr int X3R_K = 128, X3R_PITCH = X3R_K + 8;                       // weight rows: 272 B = 17 x 16 B (conflict-free b128 reads)
+constexpr int X3R_PLANE = X3_BN * X3R_PITCH;
+constexpr int X3R_LDS = 3 * X3R_PLANE * 2 + 8 * 32 * X3_EP * 4;         // 104 448 + 36 864 B
+
+__global__ void __launch_bounds__(512, 2) gemm_x3_res(GemmDesc d, const float* __restrict__ X, const uint16_t* __restrict__ Wt, int Kpad, int64_t wplane,
+                                                       const float* __restrict__ bias, float* __restrict__ Y, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) char gsm[];
+  uint16_t* Ws = reinterpret_cast<uint16_t*>(gsm);                 // [plane 3][X3_BN][X3R_PITCH]
+  const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n0 = blockIdx.y * X3_BN;
+  float* image = reinterpret_cast<float*>(gsm + 3 * X3R_PLANE * 2) + wave * (32 * X3_EP);
+  // the block's weights: 3 planes x 128 rows x K / 8 chunks of 16 bytes
+  const int cpr = d.K >> 3;
+  for (int e = tid; e < 3 * X3_BN * cpr; e += 512) {
+    const int p = e / (X3_BN * cpr), r = (e - p * X3_BN * cpr) / cpr, c = e - (p * X3_BN + r) * cpr;
+    *reinterpret_cast<u32x4*>(Ws + p * X3R_PLANE + r * X3R_PITCH + c * 8) = *reinterpret_cast<const u32x4*>(Wt + (p * wplane + (int64_t)(n0 + r) * Kpad + c * 8));
   }
+  __syncthreads();
+  const uint16_t* wsr = Ws + l31 * X3R_PITCH + h * 8;
+  const int per = d.MH * d.MW, nkt = d.K / X3_BK;
+
+  // lane l31 decodes pixel l31 of the tile; the lanes that load / store row (lane >> 3) + 8 j fetch its offsets by shuffle
+  auto decode = [&](int tile, int (&xo)[4], int (&orow)[4]) {
+    const int m = tile * 32 + l31;
+    int xoff = 0, o = -1;
+    if (m < d.M) {
+      const int img = m / per, r = m - img * per, my = r / d.MW, mx = r - my * d.MW;
+      xoff = ((img * d.IH + my * d.ay) * d.IW + mx * d.ax) * d.CI;   // rows past M read row 0, nothing is stored
+      o = ((img * d.OH + my * d.os + d.oy0) * d.OW + mx * d.os + d.ox0) * d.OC;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      xo[j] = __shfl(xoff, (lane >> 3) + 8 * j, 64) + 4 * (lane & 7);
+      orow[j] = __shfl(o, (lane >> 3) + 8 * j, 64);
+    }
+  };
+  f32x4 xr[4];
+  auto g2r = [&](const int (&xo)[4], int k0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) xr[j] = *reinterpret_cast<const f32x4*>(X + (xo[j] + k0));
+  };
+
+  int tile = (int)blockIdx.x * 8 + wave;
+  const int tstep = (int)gridDim.x * 8;
+  int xo[4], nxo[4] = {0, 0, 0, 0}, orow[4], norow[4] = {-1, -1, -1, -1};
+  if (tile < ntiles) { decode(tile, xo, orow); g2r(xo, 0); }
+  for (; tile < ntiles; tile += tstep) {
+    f32x16 accH[4], accR[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { accH[a][r] = 0.f; accR[a][r] = 0.f; }
+    const bool more_tiles = tile + tstep < ntiles;
+    if (more_tiles) decode(tile + tstep, nxo, norow);
+    for (int kt = 0; kt < nkt; ++kt) {
+      u32x4 bh[2], bm[2], bl[2];
+      x3_park_and_split(image, lane, xr, bh, bm, bl);
+      if (kt + 1 < nkt) g2r(xo, (kt + 1) * X3_BK);
+      else if (more_tiles) g2r(nxo, 0);            // the next tile's first operands ride under this tile's last MFMAs and its epilogue
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+          const uint16_t* wp = wsr + a * 32 * X3R_PITCH + kt * X3_BK + kk * 16;
+          const u32x4 ah = *reinterpret_cast<const u32x4*>(wp), am = *reinterpret_cast<const u32x4*>(wp + X3R_PLANE),
+                      al = *reinterpret_cast<const u32x4*>(wp + 2 * X3R_PLANE);
+          f32x16 c = accR[a];
+          c = mfma_bf(am, bm[kk], c);
+          c = mfma_bf(ah, bl[kk], c);
+          c = mfma_bf(al, bh[kk], c);
+          c = mfma_bf(ah, bm[kk], c);
+          c = mfma_bf(am, bh[kk], c);
+          accR[a] = c;
+          accH[a] = mfma_bf(ah, bh[kk], accH[a]);
+        }
+      }
+    }
+    x3_epilogue(d, accH, accR, bias, Y, image, n0, lane, orow);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { xo[j] = nxo[j]; orow[j] = norow[j]; }
+  }
+}
+
+bool gemm_x3_res_qualifies(const GemmDesc& d) {
+  return d.K <= X3R_K && d.K % X3_BK == 0 && d.TY * d.TX == 1 && d.cy == 0 && d.cx == 0;
 }
 
 // Qualifies: a GEMM the generic f32 kernel would run, with whole 32-deep k-tiles inside a tap and whole 128-channel blocks,
 // channel groups of 32 inside one output phase, 16-byte aligned rows on both sides, swish or linear.
 bool gemm_x3_qualifies(const GemmDesc& d) {
   return d.K >= 128 && d.CI % X3_BK == 0 && d.N % X3_BN == 0 && d.CO % 32 == 0 && d.OC % 4 == 0 && (d.act == SRCFD_ACT_SWISH || d.act == SRCFD_ACT_LINEAR) &&
-         (d.M <= 0 || (int64_t)(d.M / (d.MH * d.MW) + 1) * d.IH * d.IW * d.CI < (1ll << 31));   // 32-bit element offsets into X
+         (d.M <= 0 || ((int64_t)(d.M / (d.MH * d.MW) + 1) * d.IH * d.IW * d.CI < (1ll << 31) &&     // 32-bit element offsets into X ...
+                       (int64_t)(d.M / (d.MH * d.MW) + 1) * d.OH * d.OW * d.OC < (1ll << 31)));     // ... and into Y
 }
 
 int gemm_x3_kpad(const GemmDesc& d) { return (d.K + X3_BK - 1) / X3_BK * X3_BK; }
@@ -233,11 +353,19 @@ void gemm_x3_split_weights(const GemmDesc& d, const float* B, uint16_t* out) {
     }
 }
 
-hipError_t launch_gemm_x3(const GemmDesc& d, const float* X, const uint16_t* Wt, const float* bias, float* Y, hipStream_t s) {
+hipError_t launch_gemm_x3(const GemmDesc& d, const float* X, const uint16_t* Wt, const float* bias, float* Y, hipStream_t s, int num_cus) {
   if (d.M <= 0) return hipSuccess;
+  const int Kpad = gemm_x3_kpad(d);
+  if (gemm_x3_res_qualifies(d)) {   // short K, no taps: weights resident in LDS, one workgroup per CU and channel block walks the pixel tiles
+    hipError_t e = lds_attr_once(reinterpret_cast<const void*>(gemm_x3_res), X3R_LDS);
+    if (e != hipSuccess) return e;
+    const int ntiles = (d.M + 31) / 32, nblk = d.N / X3_BN;
+    const int gx = std::max(1, std::min((ntiles + 7) / 8, std::max(1, num_cus / nblk)));
+    hipLaunchKernelGGL(gemm_x3_res, dim3(gx, nblk), dim3(512), X3R_LDS, s, d, X, Wt, Kpad, (int64_t)d.N * Kpad, bias, Y, ntiles);
+    return hipGetLastError();
+  }
   hipError_t e = lds_attr_once(reinterpret_cast<const void*>(gemm_x3), X3_LDS);
   if (e != hipSuccess) return e;
-  const int Kpad = gemm_x3_kpad(d);
   dim3 grid((unsigned)((d.M + X3_BP - 1) / X3_BP), (unsigned)(d.N / X3_BN));
   hipLaunchKernelGGL(gemm_x3, grid, dim3(256), X3_LDS, s, d, X, Wt, Kpad, (int64_t)d.N * Kpad, bias, Y);
   return hipGetLastError();

@@ -49,7 +49,7 @@ def main():
     srcfd.SRModel.from_weights(None, dec_w, device=-1).save_h5(None, dec)
     ldc = h5.read_coarse_fields(os.path.join(GOLDEN, "coarse_ldc_Re1000_double_lid.h5"))
     bfs = h5.read_coarse_fields(os.path.join(GOLDEN, "coarse_bfs_Re400.h5"))
-    for prec in ("fp32", "bf16"):
+    for prec in ("fp32", "fp32x3", "bf16"):
         r = timeit(lambda: pl.ml_super_resolution(ldc, 10, 400, STATS, ENC, dec, precision=prec), args.calls)
         print(json.dumps({"call": "ml_super_resolution (LDC, PyCFD_ML_accelerated.py:764)", "precision": prec, **r}))
         r = timeit(lambda: pl.ml_super_resolution_bfs(bfs, 10, 400, STATS, ENC, dec, use_aspect_ratio_correction=True, lx=10.0, ly=3.0,

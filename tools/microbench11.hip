@@ -3,9 +3,10 @@
 //   reference in double on the host.  Three data sets: all products positive (a rounding BIAS shows as a drift of the
 //   mean error), signed products, and "one big + many small" (are small addends lost against a big accumulator?).
 //   mode 3 is the case that matters for kernels_x3.hip: the SAME accumulator first takes 64 MFMAs of O(1) products, then 64 MFMAs
-//   of products 2^-8 smaller (a "hi x mid" plane).  Finding (MI355X, ROCm 7.2): the small products come out with a relative
-//   error of ~2^-9 of THEIR sum, all of one sign: the adder aligns the 16 products and C to the largest exponent and truncates
-//   the bits that fall below its width.  Accumulated alone (C starts at 0), the same small products are exact to ~2^-24.
+//   of products 2^-8 smaller (a "hi x mid" plane).  Finding (MI355X, ROCm 7.2; profiles/r04/o_...): added to the big accumulator
+//   the small plane's contribution is off by up to 2.5e-4 of ITS sum (each of an MFMA's 16 products is cut at the big accumulator's
+//   last bit on the way into the adder); accumulated alone (C starts at 0) the same products are good to 6e-7.  In the split-bf16
+//   GEMM that was 3e-5 on a layer whose arithmetic is good to 1.5e-7 -- hence one accumulator set per magnitude class there.
 // build: hipcc --offload-arch=gfx950 -O2 tools/microbench11.hip -o tools/_build/microbench11
 #include <hip/hip_runtime.h>
 #include <cmath>
