@@ -755,8 +755,9 @@ def main():
             rec, y_par = job.run_sr("fp32x3", "f32", max(5, min(args.steps, 20)), min(args.warmup, 3))
             if job.rank == 0 and not args.no_cpu_baseline:
                 y_gpu["fp32x3"] = y_par[:8].cpu().numpy()
-            rec["roofline"]["note"] = ("algorithmic f32 FLOPs over the f32 MFMA peak, as for parity_path -- but ConvT#0 / ConvT#1 (45 % of the MACs) run as 6 bf16 "
-                                       "MFMAs per f32 product (kernels_x3.hip), the rest on the f32 kernels: a mixed-pipe number, for comparison with parity_path only")
+            if "roofline" in rec:   # rank 0 only
+                rec["roofline"]["note"] = ("algorithmic f32 FLOPs over the f32 MFMA peak, as for parity_path -- but ConvT#0 / ConvT#1 (45 % of the MACs) run as 6 bf16 "
+                    "MFMAs per f32 product (kernels_x3.hip), the rest on the f32 kernels: a mixed-pipe number, for comparison with parity_path only")
             return rec
         parity_x3 = leg("parity_path_x3", _parity_x3)
 
@@ -810,7 +811,8 @@ def main():
                        "weights": "encoder: reference multiBC .h5; decoder: random init seed 1 (reference decoder .h5 absent)",
                        "parallelism": f"sample-sharded x{job.world}, no collective", "backend": job.backend if job.world > 1 else None},
             "tflops_model": head["tflops_model"], "nonfinite": head["nonfinite"],
-            "kernels_ms": head.get("kernels_ms"), "kernels_ms_sum": head.get("kernels_ms_sum"), "launch_gap_ms": head.get("launch_gap_ms"),
+            "kernels_ms": head.get("kernels_ms"), "kernels_ms_sum": head.get("kernels_ms_sum"), "kernels_ms_in_step_scale": head.get("kernels_ms_in_step_scale"),
+            "launch_gap_ms": head.get("launch_gap_ms"),
             "roofline": head.get("roofline"), "last_plan": head.get("last_plan"),
             "cpu_baseline": cpu,
             "parity_path": parity, "parity_path_x3": parity_x3, "train": train, "tiled": tiled, "host_io": host_io,

@@ -114,7 +114,7 @@ struct Tail32Params {
   int nan_guard;
   unsigned long long* nonfinite;
   int out_dtype;
-  int seg;            // segments per sample (a divisor of 2H)
+  int seg;            // segments per sample, 1 .. 2H (need not divide 2H: segment s takes strips [s 2H / seg, (s + 1) 2H / seg))
   // training forward (train.hip): out = two_scale * (image - target) in f32, sum of squared errors of workgroup b in
   // sse_partial[b] (tail32_blocks() of them); aff_out / nan_guard are ignored.  null: inference.
   const float* target = nullptr;

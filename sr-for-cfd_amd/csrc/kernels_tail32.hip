@@ -141,16 +141,16 @@ __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
   // ---- job iterator: virtual samples blockIdx.x + j * gridDim.x, each a run of strips.  Plain scalars kept wave-uniform
   // (readfirstlane) so that the whole bookkeeping runs on the scalar unit.
 #define UNI(x) __builtin_amdgcn_readfirstlane(x)
-  const int S = p.seg > 1 ? p.seg : 1, L = SH / S, NV = p.n * S;
+  const int S = p.seg > 1 ? p.seg : 1, NV = p.n * S;   // segment s of a sample: strips [s SH / S, (s + 1) SH / S) -- S need not divide SH
   int it_jv = (int)blockIdx.x, it_g1 = 0;
   Strip it{0, 0, 0, 0};
   // first strip of virtual sample it_jv (warm-up strip first, unless the segment starts at the top of the image)
 #define JOB_START()                                                                     \
   do {                                                                                  \
     if (it_jv < NV) {                                                                   \
-      const int smp_ = it_jv / S, seg_ = it_jv - smp_ * S, g0_ = seg_ * L;              \
+      const int smp_ = it_jv / S, seg_ = it_jv - smp_ * S, g0_ = seg_ * SH / S;         \
       it.valid = 1; it.smp = UNI(smp_); it.g = UNI(g0_ > 0 ? g0_ - 1 : 0); it.warm = UNI(g0_ > 0 ? 1 : 0); \
-      it_g1 = UNI(g0_ + L);                                                             \
+      it_g1 = UNI((seg_ + 1) * SH / S);                                                 \
     } else it.valid = 0;                                                                \
   } while (0)
   JOB_START();
@@ -381,14 +381,15 @@ hipError_t launch_tail32(const Tail32Params& p, int num_cus, hipStream_t s) {
 int tail32_blocks(int n, int seg, int num_cus) { return (int)std::min<int64_t>((int64_t)n * (seg > 1 ? seg : 1), num_cus); }
 
 // Segments per sample for a batch of n samples of 2H strips each: the busiest workgroup walks ceil(n S / CUs) virtual
-// samples of 2H/S (+1 warm-up) strips, + 2 rounds of pipeline depth; more segments must buy 10 % to be taken.
+// samples of ceil(2H / S) (+1 warm-up) strips, + 2 rounds of pipeline depth; more segments must buy 10 % to be taken.  S need
+// not divide 2H (32 samples on 256 CUs: 8 segments of 12 or 13 strips, one virtual sample per CU -- 16 rounds; the best
+// divisor, 20, takes 20).  Every output pixel goes through the same arithmetic whatever S is.
 int tail32_segments(int n, int H, int num_cus) {
   const int SH = 2 * H;
   long best = ((long)(n + num_cus - 1) / num_cus) * SH + 2;
   int seg = 1;
   for (int cand = 2; cand <= SH; ++cand) {
-    if (SH % cand) continue;
-    const long cost = ((long)((long)n * cand + num_cus - 1) / num_cus) * (SH / cand + 1) + 2;
+    const long cost = ((long)((long)n * cand + num_cus - 1) / num_cus) * ((SH + cand - 1) / cand + 1) + 2;
     if (cost * 110 < best * 100) { best = cost; seg = cand; }
   }
   return seg;
