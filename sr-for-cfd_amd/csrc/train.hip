@@ -480,7 +480,13 @@ struct Trainer {
   float* d_dpack = nullptr; int* d_dpack_map = nullptr; size_t dpack_elems = 0;
   float* d_zero_bias = nullptr; size_t zero_bias_elems = 0;
   std::vector<float*> Z, Y;       // per compute layer (Y aliases Z for linear layers)
-  float* dbuf[3] = {nullptr, nullptr, nullptr};   // ring: dZ of layer li, li-1, li-2
+  // dZ buffers of the data-gradient chain: a ring of three (the chain may run two layers ahead of the weight gradients before it
+  // has to wait for one), sized by the largest activation the chain sees; with the fused tail one more slot holds dpred.
+  // (Measured and not kept, round 4: one slot per layer, so that the main stream never waits for the weight-gradient stream --
+  // the replayed graph then spreads over three hardware queues and the step gets SLOWER, 0.531 vs 0.508 ms at batch 8: what costs
+  // ~10 us is every fan-out edge of the graph, not the wait; tools/prof_train_step.sh.  SRCFD_TRAIN_RING=n to repeat it.)
+  std::vector<float*> dbuf;
+  int ring = 3;
   // The weight gradients of a layer (wgrad + finish) depend only on its dZ and on the forward activations, not on the
   // data-gradient chain, so they run on a second stream beside it (at micro-batch sizes no kernel fills the chip).
   hipStream_t aux = nullptr;
@@ -531,8 +537,8 @@ Trainer::~Trainer() {
   if (d_ys) (void)hipFree(d_ys);
   for (hipEvent_t e : ev_dz) (void)hipEventDestroy(e);
   for (hipEvent_t e : ev_wg) (void)hipEventDestroy(e);
-  for (void* p : {(void*)d_pack, (void*)d_pack_map, (void*)d_dpack, (void*)d_dpack_map, (void*)d_zero_bias, (void*)dbuf[0], (void*)dbuf[1],
-                  (void*)dbuf[2], (void*)d_part, (void*)d_loss_partial, (void*)d_splitk, (void*)d_pack_scale, (void*)d_tail_slabs,
+  for (float* b : dbuf) if (b) (void)hipFree(b);
+  for (void* p : {(void*)d_pack, (void*)d_pack_map, (void*)d_dpack, (void*)d_dpack_map, (void*)d_zero_bias, (void*)d_part, (void*)d_loss_partial, (void*)d_splitk, (void*)d_pack_scale, (void*)d_tail_slabs,
                   (void*)d_tail_gmap})
     if (p) (void)hipFree(p);
   for (size_t i = 0; i < Z.size(); ++i) {
@@ -722,7 +728,17 @@ static int trainer_build(Trainer& t, const Model& model, int max_batch) {
     t.Z.push_back(z);
     t.Y.push_back(y);
   }
-  for (auto*& b : t.dbuf) HIPCHECK(hipMalloc(&b, (size_t)max_batch * maxe * sizeof(float)));
+  if (t.use_tail) {
+    size_t me = t.layers.back().out_elems;   // dpred
+    for (int li = 0; li < t.tail.first_layer; ++li) me = std::max(me, t.layers[li].out_elems);
+    { const char* e = getenv("SRCFD_TRAIN_RING"); t.ring = e && atoi(e) >= 3 ? std::min(atoi(e), 16) : 3; }
+    t.dbuf.assign(t.ring + 1, nullptr);      // + the slot of dpred
+    for (auto*& b : t.dbuf) HIPCHECK(hipMalloc(&b, (size_t)max_batch * me * sizeof(float)));
+  } else {
+    t.ring = 3;
+    t.dbuf.assign(3, nullptr);
+    for (auto*& b : t.dbuf) HIPCHECK(hipMalloc(&b, (size_t)max_batch * maxe * sizeof(float)));
+  }
   { const char* e = getenv("SRCFD_TRAIN_OVERLAP"); t.overlap = !(e && atoi(e) == 0); }
   { const char* e = getenv("SRCFD_TRAIN_GRAPH"); t.use_graph = !(e && atoi(e) == 0); }
   { const char* e = getenv("SRCFD_TRAIN_FUSE"); t.fuse_epilogues = !(e && atoi(e) == 0); }
@@ -817,7 +833,7 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
   const float* tp = t.d_pack + t.tail_pack_off;
   if (t.use_tail) {
     Tail32Params q;
-    q.in = t.Y[Lg - 1]; q.out = t.dbuf[1]; q.n = n; q.H = t.tail.H; q.W = t.tail.W;
+    q.in = t.Y[Lg - 1]; q.out = t.dbuf[t.ring]; q.n = n; q.H = t.tail.H; q.W = t.tail.W;
     q.w1f = tp + t.tail.t32_w1; q.b1 = tp + t.tail.t32_b1; q.w2f = tp + t.tail.t32_w2; q.b2 = tp + t.tail.t32_b2;
     q.w3f = tp + t.tail.t32_w3; q.b3 = tp + t.tail.t32_b3; q.wc = tp + t.tail.t32_wc;
     q.aff_out = nullptr; q.nan_guard = 0; q.nonfinite = nullptr; q.out_dtype = SRCFD_F32;
@@ -844,7 +860,7 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
   if (t.overlap && t.dpack_elems) HIPCHECK(hipStreamWaitEvent(s, t.ev_dpack, 0));
   if (t.use_tail) {      // every gradient of the last four layers + dZ of layer Lg - 1, from dpred (dbuf[1]) and that layer's Z / Y
     TailBwdParams q;
-    q.y1 = t.Y[Lg - 1]; q.z1 = t.Z[Lg - 1]; q.dpred = t.dbuf[1]; q.dz1 = t.dbuf[0]; q.slabs = t.d_tail_slabs;
+    q.y1 = t.Y[Lg - 1]; q.z1 = t.Z[Lg - 1]; q.dpred = t.dbuf[t.ring]; q.dz1 = t.dbuf[0]; q.slabs = t.d_tail_slabs;
     q.wf = tp + t.tail.wf; q.wb = tp + t.tail.wb; q.wt = tp + t.tail.wt; q.bias = tp + t.tail.bias;
     q.n = n; q.H = t.tail.H; q.W = t.tail.W;
     HIPCHECK(launch_tail_bwd32(q, t.num_cus, s));
@@ -892,9 +908,9 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
       const DgradOp& dg = t.dops[li - 1];
       GemmDesc d = dg.d;
       d.M = n * d.MH * d.MW;
-      const int nxt = (cur + 1) % 3;
-      // the ring slot about to be overwritten held dZ of layer li+2: its weight gradient must have read it
-      if (t.overlap && li + 2 <= Lg - 1) HIPCHECK(hipStreamWaitEvent(s, t.ev_wg[li + 2], 0));
+      const int nxt = (cur + 1) % t.ring;
+      // the ring slot about to be overwritten held dZ of layer li + ring - 1: its weight gradient must have read it
+      if (t.overlap && li + t.ring - 1 <= Lg - 1) HIPCHECK(hipStreamWaitEvent(s, t.ev_wg[li + t.ring - 1], 0));
       EpiAux aux;
       if (t.fuse_epilogues && t.layers[li - 1].swish && gemm_supports_epi_aux(d)) { aux.mode = 2; aux.zaux = t.Z[li - 1]; dz_done = true; }
       HIPCHECK(launch_gemm_mfma(d, dZ, t.d_dpack + dg.w_off, t.d_zero_bias, t.dbuf[nxt], s, t.d_splitk, t.splitk_floats, false, aux));
