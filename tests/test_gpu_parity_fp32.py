@@ -232,6 +232,50 @@ def test_single_layers(srcfd, oracle, case, precision):
     assert oracle.rel_l2(y, ref) <= TOL_FP32
 
 
+X3_LAYER_CASES = [
+    # layers the split-bf16 GEMM qualifies for (K >= 128, Cin % 32 == 0, N % 128 == 0), one per gather shape of the implicit GEMM
+    ("x3_conv_same_s1", "conv2d", 3, 1, True, 64, 128, (9, 7)),             # taps leave the image on every side
+    ("x3_conv_same_s2_asym_pad", "conv2d", 3, 2, True, 32, 128, (10, 10)),  # TF-SAME stride 2: pad bottom / right only
+    ("x3_conv_valid", "conv2d", 3, 1, False, 32, 128, (8, 8)),
+    ("x3_convT_3x3_s2_overlap", "conv2d_transpose", 3, 2, False, 256, 128, (5, 6)),   # four output phases, 4 / 2 / 2 / 1 taps
+    ("x3_convT_2x2_s2", "conv2d_transpose", 2, 2, False, 128, 64, (7, 5)),            # merged phases, the weights-resident kernel
+    ("x3_convT_2x2_s2_k256", "conv2d_transpose", 2, 2, False, 256, 32, (6, 6)),       # merged phases with K > 128: the staged kernel
+    ("x3_convT_4x4_s2", "conv2d_transpose", 4, 2, False, 64, 128, (5, 5)),
+]
+
+
+@pytest.mark.parametrize("act", ["swish", "linear"])
+@pytest.mark.parametrize("case", X3_LAYER_CASES, ids=[c[0] for c in X3_LAYER_CASES])
+def test_single_layers_split_bf16(srcfd, oracle, case, act):
+    """gemm_x3 / gemm_x3_res (csrc/kernels_x3.hip) as a generic layer kernel: 70 samples (the precision uses it from 64 on), against
+    the float64 oracle at the f32 bar AND at least as close as the f32 MFMA kernel; the profile shows the kernel ran."""
+    require_gpu(srcfd)
+    _, kind, k, stride, same, cin, cout, (h, w) = case
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(case[0].encode()))
+    if kind == "conv2d":
+        wt = rng.standard_normal((k, k, cin, cout)).astype(np.float32) / np.sqrt(k * k * cin)
+    else:
+        wt = rng.standard_normal((k, k, cout, cin)).astype(np.float32) / np.sqrt(cin)
+    b = rng.standard_normal(cout).astype(np.float32) * 0.1
+    x = rng.standard_normal((70, h, w, cin)).astype(np.float32)
+    m = srcfd.SRModel.from_layers([dict(kind=kind, k=k, stride=stride, same=same, act=act, w=wt, b=b)], (h, w, cin), device=0)
+    xd = x.astype(np.float64)
+    ref = oracle.conv2d(xd, wt, b, stride, "same" if same else "valid", act) if kind == "conv2d" else oracle.conv2d_transpose(xd, wt, b, stride, "valid", act)
+    m.precision = "fp32"
+    e32 = oracle.rel_l2(m.predict(x), ref)
+    m.precision = "fp32x3"
+    m.set_profiling(True)
+    y = m.predict(x)
+    names = [nm for nm, _ in m.get_profile()]
+    m.set_profiling(False)
+    assert any(nm.endswith("(x3)") for nm in names), names
+    ex3 = oracle.rel_l2(y, ref)
+    print(f"{case[0]} {act}: fp32 {e32:.2e} x3 {ex3:.2e}")
+    assert y.shape == ref.shape and ex3 <= TOL_FP32 and ex3 <= 1.5 * e32 + 1e-7
+    np.testing.assert_array_equal(m.predict(x[3:68]), y[3:68])       # rows independent of where the tile boundaries fall
+
+
 def test_dense_flatten_reshape_chain(srcfd, oracle):
     require_gpu(srcfd)
     rng = np.random.default_rng(5)
