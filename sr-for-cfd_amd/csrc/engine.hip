@@ -261,6 +261,38 @@ static void plan_x3(Model& m) {
     m.pack_x3.resize(m.pack_x3.size() + (size_t)3 * d.N * gemm_x3_kpad(d));
     gemm_x3_split_weights(d, m.pack.data() + m.ops[i].w_off, m.pack_x3.data() + m.x3_off[i]);
   }
+  // the streaming tail's first layer (kernels_tail32.hip, X3): w1 x log2(e), rounded to f32 as in plan_tail32, then split
+  //   w1x[((((ty1*2 + tx1)*2 + t)*2 + c)*3 + plane)*64 + lane][j] = plane(W1[2 ty1 + tx1][co 16t + m][ci 32c + 8 kg + j]),  lane = (m, kg)
+  m.t32_w1x = -1;
+  if (m.tail32_op >= 0) {
+    const Layer& L1 = m.desc.layers[m.ops[m.tail32_op].layer];
+    const double LOG2E = 1.4426950408889634;
+    while (m.pack_x3.size() % 64) m.pack_x3.push_back(0);
+    m.t32_w1x = (int64_t)m.pack_x3.size();
+    m.pack_x3.resize(m.pack_x3.size() + (size_t)2 * 2 * 2 * 2 * 3 * 64 * 8);
+    uint16_t* out = m.pack_x3.data() + m.t32_w1x;
+    for (int ty1 = 0; ty1 < 2; ++ty1)
+      for (int tx1 = 0; tx1 < 2; ++tx1)
+        for (int t = 0; t < 2; ++t)
+          for (int c = 0; c < 2; ++c)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int j = 0; j < 8; ++j) {
+                const int mm = lane & 15, kg = lane >> 4, tap = 2 * ty1 + tx1;
+                const float w = (float)(L1.kernel[((size_t)tap * 32 + 16 * t + mm) * 64 + 32 * c + 8 * kg + j] * LOG2E);
+                uint32_t b0, b1, b2;
+                std::memcpy(&b0, &w, 4); b0 &= 0xffff0000u;
+                float hi; std::memcpy(&hi, &b0, 4);
+                const float r1 = w - hi;
+                std::memcpy(&b1, &r1, 4); b1 &= 0xffff0000u;
+                float mid; std::memcpy(&mid, &b1, 4);
+                const float r2 = r1 - mid;
+                std::memcpy(&b2, &r2, 4);
+                const size_t frag = (size_t)((((ty1 * 2 + tx1) * 2 + t) * 2 + c) * 3);
+                out[((frag + 0) * 64 + lane) * 8 + j] = (uint16_t)(b0 >> 16);
+                out[((frag + 1) * 64 + lane) * 8 + j] = (uint16_t)(b1 >> 16);
+                out[((frag + 2) * 64 + lane) * 8 + j] = (uint16_t)(b2 >> 16);
+              }
+  }
 }
 
 // enc32 (kernels_enc32.hip): the encoder's four compute layers as one launch.  conv2d_1's weights are re-ordered into
@@ -495,7 +527,8 @@ int Model::forward_generic(const float* x_dev, int n, const float* aff_in, const
       tp.w3f = d_pack + t32_w3; tp.b3 = d_pack + t32_b3; tp.wc = d_pack + t32_wc;
       tp.aff_out = aff_out; tp.nan_guard = flags & SRCFD_FLAG_NAN_GUARD; tp.nonfinite = nonfinite; tp.out_dtype = out_dtype;
       tp.seg = tail32_segments(n, d.MH, num_cus);
-      const std::string nm = op.name + "+" + ops[i + 1].name + "+" + ops[i + 2].name + "+" + ops[i + 3].name;
+      if (x3 && d_pack_x3 && t32_w1x >= 0 && n >= 64) tp.w1x = d_pack_x3 + t32_w1x;   // SRCFD_PREC_FP32X3: the first layer on the bf16 matrix cores
+      const std::string nm = op.name + "+" + ops[i + 1].name + "+" + ops[i + 2].name + "+" + ops[i + 3].name + (tp.w1x ? "(x3)" : "");
       return launch(nm.c_str(), s, [&] { return launch_tail32(tp, num_cus, s); });
     }
     static const bool no_pair = [] { const char* e = getenv("SRCFD_NO_PAIR"); return e && atoi(e) != 0; }();

@@ -120,6 +120,10 @@ struct Tail32Params {
   const float* target = nullptr;
   float two_scale = 0.f;
   double* sse_partial = nullptr;
+  // SRCFD_PREC_FP32X3: the first layer's weights (x log2 e, like w1f) split exactly into three bf16 planes, as
+  // v_mfma_f32_16x16x32_bf16 A fragments: [tap row ty1 2][tap column tx1 2][m-tile t 2][k-step c 2][plane 3][64 lanes] x 16 B,
+  // lane (m, kg) element j = plane(W1[2 ty1 + tx1][co 16 t + m][ci 32 c + 8 kg + j]).  null: the f32 MFMAs of w1f.
+  const uint16_t* w1x = nullptr;
 };
 hipError_t launch_tail32(const Tail32Params& p, int num_cus, hipStream_t s);
 int tail32_segments(int n, int H, int num_cus);

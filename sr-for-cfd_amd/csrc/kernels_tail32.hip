@@ -89,7 +89,36 @@ struct Strip {
 // TRAIN (train.hip, forward pass of a training step): the epilogue turns the image into the loss gradient instead of
 // de-standardising it -- out = dpred = two_scale * (pred - target), and every workgroup leaves the sum of its squared
 // errors (float64, fixed order: the row -> workgroup assignment is static) in sse_partial[blockIdx.x].
-template <int OUT, bool TRAIN>  // OUT: 0 f32, 1 bf16, 2 f16
+// X3 (SRCFD_PREC_FP32X3): the first layer (ConvT 64 -> 32, a third of the kernel's f32 MFMA cycles) as six bf16 MFMAs per product
+// on operands split exactly into three bf16 terms, as in kernels_x3.hip: v_mfma_f32_16x16x32_bf16, K = 64 = two k-steps, the hi x hi
+// products in an accumulator of their own.  The input tile is split once per round (16 values per lane); the hi and mid weight
+// planes of both tap rows are resident (64 registers, what the f32 fragments took), the lo plane of the round's tap row is
+// fetched at the start of the round and used last.  bf16 MFMAs run under the vector work of the wave that issues them, f32 ones
+// do not: the layer leaves the f32 matrix pipe (1 024 cycles per item) for ~110 vector instructions.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8_t32 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x4 mfma16bf(const u32x4& a, const u32x4& b, const f32x4& c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s16x8_t32, a), __builtin_bit_cast(s16x8_t32, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ void split8_t32(const f32x4& v0, const f32x4& v1, u32x4& fh, u32x4& fm, u32x4& fl) {
+  uint32_t hm[8], mm[8], lm[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float x = i < 4 ? v0[i & 3] : v1[i & 3];
+    hm[i] = __builtin_bit_cast(uint32_t, x) & 0xffff0000u;
+    const float r1 = x - __builtin_bit_cast(float, hm[i]);
+    mm[i] = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
+    lm[i] = __builtin_bit_cast(uint32_t, r1 - __builtin_bit_cast(float, mm[i]));
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    fh[q] = __builtin_amdgcn_perm(hm[2 * q + 1], hm[2 * q], 0x07060302u);
+    fm[q] = __builtin_amdgcn_perm(mm[2 * q + 1], mm[2 * q], 0x07060302u);
+    fl[q] = __builtin_amdgcn_perm(lm[2 * q + 1], lm[2 * q], 0x07060302u);
+  }
+}
+
+template <int OUT, bool TRAIN, bool X3 = false>  // OUT: 0 f32, 1 bf16, 2 f16
 __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, n = lane & 15, rg = lane >> 4;
@@ -107,16 +136,27 @@ __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
   const bool px_ok = px < W;
   const int pxc = px_ok ? px : W - 1;
   const bool tile_on = 16 * tile < W;   // wave-uniform: tiles wholly past the row do nothing
-  float wA[2][2][16];
+  float wA[2][2][X3 ? 1 : 16];
+  u32x4 wH[2][2][2], wM[2][2][2];          // X3: [ty1][m-tile t][k-step c], hi and mid planes
+  const u32x4* w1x = reinterpret_cast<const u32x4*>(p.w1x) + lane;   // [(((ty1*2 + tx1)*2 + t)*2 + c)*3 + plane][64 lanes]
   const float* wB = reinterpret_cast<const float*>(smem + R_W2) + lane;   // [(2 ty2 + tx2) * 8 + ks][64]
   const float* wC = reinterpret_cast<const float*>(smem + R_W3) + lane;   // [u * 4 + i][64]
   f32x4 bA[2], bB, bC;
 #pragma unroll
   for (int ty1 = 0; ty1 < 2; ++ty1)
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t) {
+      if (X3) {
 #pragma unroll
-      for (int s = 0; s < 16; ++s) wA[ty1][t][s] = p.w1f[((((2 * ty1 + tx1) * 2 + t) * 16) + s) * 64 + lane];
+        for (int c = 0; c < 2; ++c) {
+          wH[ty1][t][c] = w1x[((((ty1 * 2 + tx1) * 2 + t) * 2 + c) * 3 + 0) * 64];
+          wM[ty1][t][c] = w1x[((((ty1 * 2 + tx1) * 2 + t) * 2 + c) * 3 + 1) * 64];
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < 16; ++s) wA[ty1][t][s] = p.w1f[((((2 * ty1 + tx1) * 2 + t) * 16) + s) * 64 + lane];
+      }
+    }
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -157,9 +197,11 @@ __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
   Strip cur = it, d1{0, 0, 0, 0}, d2{0, 0, 0, 0};
 
   auto load_x = [&](const Strip& s, f32x4 (&x)[4]) {
-    const float* src = p.in + ((((size_t)s.smp * H + (s.g >> 1)) * W + pxc) * 64 + 16 * rg);
+    // f32 MFMAs: channels 16 rg + 0..15 (k-step s contracts channel 16 kg + s); X3: channels 8 rg + 0..7 and 32 + 8 rg + 0..7 (the two
+    // 32-deep k-steps of v_mfma_f32_16x16x32_bf16: lane group kg holds k = 8 kg + j)
+    const float* src = p.in + ((((size_t)s.smp * H + (s.g >> 1)) * W + pxc) * 64 + (X3 ? 8 : 16) * rg);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) x[q] = *reinterpret_cast<const f32x4*>(src + 4 * q);
+    for (int q = 0; q < 4; ++q) x[q] = *reinterpret_cast<const f32x4*>(src + (X3 ? 32 * (q >> 1) + 4 * (q & 1) : 4 * q));
   };
   f32x4 xs[4], xn[4];
 #pragma unroll
@@ -236,6 +278,36 @@ __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
         a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wA[ty1][1][s], xv, a1, 0, 0, 0);
       }
     };
+    // X3: the round's input split into three bf16 planes, the lo weight plane of this round's tap row on its way
+    u32x4 xh[2], xm[2], xl[2], wL[2][2];
+    f32x4 r0 = {0.f, 0.f, 0.f, 0.f}, r1 = {0.f, 0.f, 0.f, 0.f};   // the small products' accumulators (a0 / a1 take hi x hi and the bias)
+    if (X3) {
+      const int ty1r = cur.g & 1;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) wL[t][c] = w1x[((((ty1r * 2 + tx1) * 2 + t) * 2 + c) * 3 + 2) * 64];
+      split8_t32(xs[0], xs[1], xh[0], xm[0], xl[0]);
+      split8_t32(xs[2], xs[3], xh[1], xm[1], xl[1]);
+    }
+    auto layer1x = [&](auto TY1, auto PART) {   // PART 0: mid x mid, hi x lo; 1: hi x mid, mid x hi, hi x hi; 2: lo x hi (the late plane), sets meet
+      constexpr int ty1 = decltype(TY1)::value;
+      constexpr int part = decltype(PART)::value;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        if (part == 0) {
+          r0 = mfma16bf(wM[ty1][0][c], xm[c], r0); r1 = mfma16bf(wM[ty1][1][c], xm[c], r1);
+          r0 = mfma16bf(wH[ty1][0][c], xl[c], r0); r1 = mfma16bf(wH[ty1][1][c], xl[c], r1);
+        } else if (part == 1) {
+          r0 = mfma16bf(wH[ty1][0][c], xm[c], r0); r1 = mfma16bf(wH[ty1][1][c], xm[c], r1);
+          r0 = mfma16bf(wM[ty1][0][c], xh[c], r0); r1 = mfma16bf(wM[ty1][1][c], xh[c], r1);
+          a0 = mfma16bf(wH[ty1][0][c], xh[c], a0); a1 = mfma16bf(wH[ty1][1][c], xh[c], a1);
+        } else {
+          r0 = mfma16bf(wL[0][c], xh[c], r0); r1 = mfma16bf(wL[1][c], xh[c], r1);
+        }
+      }
+      if (part == 2) { a0 = a0 + r0; a1 = a1 + r1; }
+    };
     auto window_row = [&](auto DY, const int ro) {
       constexpr int dy = decltype(DY)::value;
       const char* rowp = smem + ro;
@@ -267,13 +339,16 @@ __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
     const size_t o_row = ((size_t)d_smp * OHs + d_yl) * OW;
     f32x4 tgt = {0.f, 0.f, 0.f, 0.f};
     auto front = [&](auto TY1) {
-      layer1(TY1, std::integral_constant<int, 0>{}, std::integral_constant<int, 6>{});
+      if (X3) layer1x(TY1, std::integral_constant<int, 0>{});
+      else layer1(TY1, std::integral_constant<int, 0>{}, std::integral_constant<int, 6>{});
       window_row(std::integral_constant<int, 0>{}, ro0);
       load_x(ldx, xn);   // behind the asm of window_row (a memory clobber): cannot be hoisted above the first MFMA
       if (TRAIN) tgt = *reinterpret_cast<const f32x4*>(p.target + o_row + 4 * (d_lane ? db : 0));
-      layer1(TY1, std::integral_constant<int, 6>{}, std::integral_constant<int, 11>{});
+      if (X3) layer1x(TY1, std::integral_constant<int, 1>{});
+      else layer1(TY1, std::integral_constant<int, 6>{}, std::integral_constant<int, 11>{});
       window_row(std::integral_constant<int, 1>{}, ro1);
-      layer1(TY1, std::integral_constant<int, 11>{}, std::integral_constant<int, 16>{});
+      if (X3) layer1x(TY1, std::integral_constant<int, 2>{});
+      else layer1(TY1, std::integral_constant<int, 11>{}, std::integral_constant<int, 16>{});
       window_row(std::integral_constant<int, 2>{}, ro2);
     };
     if (cur.g & 1) front(std::integral_constant<int, 1>{});
@@ -368,7 +443,9 @@ __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
 hipError_t launch_tail32(const Tail32Params& p, int num_cus, hipStream_t s) {
   if (p.n == 0) return hipSuccess;
   void (*fn)(Tail32Params) = p.target ? tail32<0, true>
-                             : (p.out_dtype == SRCFD_F32 ? tail32<0, false> : (p.out_dtype == SRCFD_BF16 ? tail32<1, false> : tail32<2, false>));
+                             : (p.out_dtype == SRCFD_F32 ? (p.w1x ? tail32<0, false, true> : tail32<0, false>)
+                                : (p.out_dtype == SRCFD_BF16 ? (p.w1x ? tail32<1, false, true> : tail32<1, false>) : (p.w1x ? tail32<2, false, true> : tail32<2, false>)));
+  if (p.target && p.w1x) return hipErrorInvalidValue;
   if (p.target && (p.out_dtype != SRCFD_F32 || !p.sse_partial)) return hipErrorInvalidValue;
   hipError_t e = lds_attr_once(reinterpret_cast<const void*>(fn), T32_LDS);
   if (e != hipSuccess) return e;
