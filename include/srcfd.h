@@ -43,10 +43,11 @@ typedef enum {
   SRCFD_PREC_BF16 = 1,       /* bf16 operands, f32 accumulate, fused tail: throughput path             */
   SRCFD_PREC_FP32_NAIVE = 2, /* one thread per output, f32 FMA chain: bring-up / cross-check           */
   SRCFD_PREC_F16 = 3,        /* f16 operands, f32 accumulate (BASELINE config 5)                        */
-  SRCFD_PREC_FP32X3 = 4      /* f32 storage and vector math; the wide decoder GEMMs (ConvT#0, ConvT#1) as six
-                                bf16 MFMAs on operands split exactly into three bf16 terms (kernels_x3.hip):
-                                f32-grade results (<= 1e-5 vs the float64 oracle, measured 4e-7) at 6/16 of the
-                                f32 matrix time.  Everything else runs the SRCFD_PREC_FP32 kernels.          */
+  SRCFD_PREC_FP32X3 = 4      /* f32 storage and vector math; the wide decoder GEMMs (ConvT#0, ConvT#1) and the
+                                streaming tail's first layer as six bf16 MFMAs on operands split exactly into
+                                three bf16 terms (kernels_x3.hip, tail32<X3>): f32-grade results (<= 1e-5 vs the
+                                float64 oracle, measured 5e-7) at 6/16 of the f32 matrix time, from 64 samples per
+                                call on; smaller calls and everything else run the SRCFD_PREC_FP32 kernels.   */
 } srcfd_precision;
 
 typedef enum {
