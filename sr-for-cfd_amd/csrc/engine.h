@@ -93,7 +93,7 @@ struct Model {
   // SRCFD_PREC_FP32X3: ops the split-bf16 GEMM takes (kernels_x3.hip): x3_off[i] = offset of op i's three weight planes in pack_x3
   // (elements), or -1.  Built at create, uploaded with the f32 pack.
   std::vector<int64_t> x3_off;
-  int64_t t32_w1x = -1;   // the streaming tail's first-layer fragments in pack_x3 (kernels.h, Tail32Params::w1x), or -1
+  int64_t t32_w1x = -1, t32_w2x = -1;   // the streaming tail's first- and second-layer fragments in pack_x3 (kernels.h, Tail32Params::w1x / w2x), or -1
   std::vector<uint16_t> pack_x3;
   uint16_t* d_pack_x3 = nullptr;
 

@@ -263,8 +263,31 @@ static void plan_x3(Model& m) {
   }
   // the streaming tail's first layer (kernels_tail32.hip, X3): w1 x log2(e), rounded to f32 as in plan_tail32, then split
   //   w1x[((((ty1*2 + tx1)*2 + t)*2 + c)*3 + plane)*64 + lane][j] = plane(W1[2 ty1 + tx1][co 16t + m][ci 32c + 8 kg + j]),  lane = (m, kg)
-  m.t32_w1x = -1;
+  m.t32_w1x = m.t32_w2x = -1;
+  auto split3 = [](float w, uint16_t (&o)[3]) {
+    uint32_t b0, b1, b2;
+    std::memcpy(&b0, &w, 4); b0 &= 0xffff0000u;
+    float hi; std::memcpy(&hi, &b0, 4);
+    const float r1 = w - hi;
+    std::memcpy(&b1, &r1, 4); b1 &= 0xffff0000u;
+    float mid; std::memcpy(&mid, &b1, 4);
+    const float r2 = r1 - mid;
+    std::memcpy(&b2, &r2, 4);
+    o[0] = (uint16_t)(b0 >> 16); o[1] = (uint16_t)(b1 >> 16); o[2] = (uint16_t)(b2 >> 16);
+  };
   if (m.tail32_op >= 0) {
+    const Layer& L2 = m.desc.layers[m.ops[m.tail32_op + 1].layer];
+    while (m.pack_x3.size() % 64) m.pack_x3.push_back(0);
+    m.t32_w2x = (int64_t)m.pack_x3.size();
+    m.pack_x3.resize(m.pack_x3.size() + (size_t)4 * 3 * 64 * 8);
+    for (int tap = 0; tap < 4; ++tap)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int j = 0; j < 8; ++j) {
+          const int mm = lane & 15, kg = lane >> 4, ci = j < 4 ? 4 * kg + j : 16 + 4 * kg + (j - 4);
+          uint16_t o[3];
+          split3(L2.kernel[((size_t)tap * 16 + mm) * 32 + ci], o);
+          for (int pl = 0; pl < 3; ++pl) m.pack_x3[m.t32_w2x + ((size_t)(tap * 3 + pl) * 64 + lane) * 8 + j] = o[pl];
+        }
     const Layer& L1 = m.desc.layers[m.ops[m.tail32_op].layer];
     const double LOG2E = 1.4426950408889634;
     while (m.pack_x3.size() % 64) m.pack_x3.push_back(0);
@@ -527,7 +550,10 @@ int Model::forward_generic(const float* x_dev, int n, const float* aff_in, const
       tp.w3f = d_pack + t32_w3; tp.b3 = d_pack + t32_b3; tp.wc = d_pack + t32_wc;
       tp.aff_out = aff_out; tp.nan_guard = flags & SRCFD_FLAG_NAN_GUARD; tp.nonfinite = nonfinite; tp.out_dtype = out_dtype;
       tp.seg = tail32_segments(n, d.MH, num_cus);
-      if (x3 && d_pack_x3 && t32_w1x >= 0 && n >= 64) tp.w1x = d_pack_x3 + t32_w1x;   // SRCFD_PREC_FP32X3: the first layer on the bf16 matrix cores
+      if (x3 && d_pack_x3 && t32_w1x >= 0 && t32_w2x >= 0 && n >= 64) {   // SRCFD_PREC_FP32X3: the first two layers on the bf16 matrix cores
+        tp.w1x = d_pack_x3 + t32_w1x;
+        tp.w2x = d_pack_x3 + t32_w2x;
+      }
       const std::string nm = op.name + "+" + ops[i + 1].name + "+" + ops[i + 2].name + "+" + ops[i + 3].name + (tp.w1x ? "(x3)" : "");
       return launch(nm.c_str(), s, [&] { return launch_tail32(tp, num_cus, s); });
     }

@@ -124,6 +124,9 @@ struct Tail32Params {
   // v_mfma_f32_16x16x32_bf16 A fragments: [tap row ty1 2][tap column tx1 2][m-tile t 2][k-step c 2][plane 3][64 lanes] x 16 B,
   // lane (m, kg) element j = plane(W1[2 ty1 + tx1][co 16 t + m][ci 32 c + 8 kg + j]).  null: the f32 MFMAs of w1f.
   const uint16_t* w1x = nullptr;
+  // ... and the second layer's (unscaled, like w2f): [tap2 4][plane 3][64 lanes] x 16 B, lane (m, kg) element j =
+  // plane(W2[tap2][co m][ci j < 4 ? 4 kg + j : 16 + 4 kg + j - 4]) -- the k order of the first layer's accumulators.  Both or neither.
+  const uint16_t* w2x = nullptr;
 };
 hipError_t launch_tail32(const Tail32Params& p, int num_cus, hipStream_t s);
 int tail32_segments(int n, int H, int num_cus);

@@ -52,6 +52,17 @@ constexpr int R_W3 = R_W2 + 4 * 8 * 64 * 4;       // (held in registers they cos
 constexpr int R_DUMP = R_W3 + 2 * 4 * 64 * 4;     // 64 granules: where lanes / rounds with nothing to store write (keeps the body branch-free)
 constexpr int T32_LDS = R_DUMP + 64 * 16;         // 163648
 static_assert(T32_LDS <= 160 * 1024, "tail32 LDS budget");
+// X3 layout: no all-zero row (the output conv skips window rows outside the image instead of reading zeros: 13.8 KB), which makes
+// room for the second layer's THREE bf16 weight planes (12 KB instead of 8 KB of f32 fragments)
+template <bool X3> struct T32Lay {
+  static constexpr int ZROW = X3 ? -1 : R_ZROW;                       // "no row": X3 skips it
+  static constexpr int WC = X3 ? R_ROWS * R_ROW : R_WC;
+  static constexpr int W2 = WC + 320;
+  static constexpr int W3 = W2 + (X3 ? 4 * 3 * 64 * 16 : 4 * 8 * 64 * 4);
+  static constexpr int DUMP = W3 + 2 * 4 * 64 * 4;
+  static constexpr int LDS = DUMP + 64 * 16;
+};
+static_assert(T32Lay<true>::LDS <= 160 * 1024 && T32Lay<false>::LDS == T32_LDS, "tail32 LDS budget");
 
 __device__ __forceinline__ void lds_barrier32() {  // LDS traffic complete, global loads / stores stay in flight
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -89,7 +100,7 @@ struct Strip {
 // TRAIN (train.hip, forward pass of a training step): the epilogue turns the image into the loss gradient instead of
 // de-standardising it -- out = dpred = two_scale * (pred - target), and every workgroup leaves the sum of its squared
 // errors (float64, fixed order: the row -> workgroup assignment is static) in sse_partial[blockIdx.x].
-// X3 (SRCFD_PREC_FP32X3): the first layer (ConvT 64 -> 32, a third of the kernel's f32 MFMA cycles) as six bf16 MFMAs per product
+// X3 (SRCFD_PREC_FP32X3): the first TWO layers (ConvT 64 -> 32 -> 16: two thirds of the kernel's f32 MFMA cycles) as six bf16 MFMAs per product
 // on operands split exactly into three bf16 terms, as in kernels_x3.hip: v_mfma_f32_16x16x32_bf16, K = 64 = two k-steps, the hi x hi
 // products in an accumulator of their own.  The input tile is split once per round (16 values per lane); the hi and mid weight
 // planes of both tap rows are resident (64 registers, what the f32 fragments took), the lo plane of the round's tap row is
@@ -125,10 +136,12 @@ __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = p.H, W = p.W, SH = 2 * H, OW = 8 * W, OHs = 8 * H;
 
-  for (int i = tid; i < R_WC / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
-  if (tid < 80) reinterpret_cast<float*>(smem + R_WC)[tid] = tid < 73 ? p.wc[tid] : 0.f;
-  for (int i = tid; i < 4 * 8 * 64; i += 512) reinterpret_cast<float*>(smem + R_W2)[i] = p.w2f[i];
-  reinterpret_cast<float*>(smem + R_W3)[tid] = p.w3f[tid];   // 2 * 4 * 64 = 512 floats
+  typedef T32Lay<X3> LY;
+  for (int i = tid; i < LY::WC / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
+  if (tid < 80) reinterpret_cast<float*>(smem + LY::WC)[tid] = tid < 73 ? p.wc[tid] : 0.f;
+  if (X3) { for (int i = tid; i < 4 * 3 * 64; i += 512) reinterpret_cast<u32x4*>(smem + LY::W2)[i] = reinterpret_cast<const u32x4*>(p.w2x)[i]; }
+  else { for (int i = tid; i < 4 * 8 * 64; i += 512) reinterpret_cast<float*>(smem + LY::W2)[i] = p.w2f[i]; }
+  reinterpret_cast<float*>(smem + LY::W3)[tid] = p.w3f[tid];   // 2 * 4 * 64 = 512 floats
 
   // ---- P role: item = (tile, tx1) ----
   const int tile = wave & 3, tx1 = wave >> 2;
@@ -139,8 +152,9 @@ __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
   float wA[2][2][X3 ? 1 : 16];
   u32x4 wH[2][2][2], wM[2][2][2];          // X3: [ty1][m-tile t][k-step c], hi and mid planes
   const u32x4* w1x = reinterpret_cast<const u32x4*>(p.w1x) + lane;   // [(((ty1*2 + tx1)*2 + t)*2 + c)*3 + plane][64 lanes]
-  const float* wB = reinterpret_cast<const float*>(smem + R_W2) + lane;   // [(2 ty2 + tx2) * 8 + ks][64]
-  const float* wC = reinterpret_cast<const float*>(smem + R_W3) + lane;   // [u * 4 + i][64]
+  const float* wB = reinterpret_cast<const float*>(smem + LY::W2) + lane;   // [(2 ty2 + tx2) * 8 + ks][64]
+  const u32x4* wBx = reinterpret_cast<const u32x4*>(smem + LY::W2) + lane;    // X3: [(2 ty2 + tx2) * 3 + plane][64]
+  const float* wC = reinterpret_cast<const float*>(smem + LY::W3) + lane;   // [u * 4 + i][64]
   f32x4 bA[2], bB, bC;
 #pragma unroll
   for (int ty1 = 0; ty1 < 2; ++ty1)
@@ -174,7 +188,7 @@ __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
   const int d_c = (4 * (dbc & 1)) * R_PLANE + ((dbc >> 1) + 1) * 16;                                   // columns X0 .. X0+3: + j * R_PLANE
   const int d_l = (dbc & 1) ? 3 * R_PLANE + ((dbc >> 1) + 1) * 16 : 7 * R_PLANE + (dbc >> 1) * 16;      // column X0 - 1
   const int d_r = (dbc & 1) ? ((dbc >> 1) + 2) * 16 : 4 * R_PLANE + ((dbc >> 1) + 1) * 16;              // column X0 + 4
-  const f32x4* wk = reinterpret_cast<const f32x4*>(smem + R_WC);   // [tap][half]
+  const f32x4* wk = reinterpret_cast<const f32x4*>(smem + LY::WC);   // [tap][half]
   unsigned bad_total = 0;
   double sse = 0.0;
 
@@ -238,12 +252,12 @@ __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
         d_smp = d2.smp; d_yl = 4 * d2.g + 3;
         ro0 = ((base - 2) % R_ROWS) * R_ROW;
         ro1 = ((base - 1) % R_ROWS) * R_ROW;
-        ro2 = below ? (base % R_ROWS) * R_ROW : R_ZROW;
+        ro2 = below ? (base % R_ROWS) * R_ROW : LY::ZROW;
       } else {
         d_on = d1.valid && !d1.warm;
         d_smp = d1.smp; d_yl = 4 * d1.g + dq - 1;
         const bool above = dq > 1 || (d2.valid && d2.smp == d1.smp && d2.g + 1 == d1.g);   // else: top of the image
-        ro0 = above ? ((base + dq - 2) % R_ROWS) * R_ROW : R_ZROW;
+        ro0 = above ? ((base + dq - 2) % R_ROWS) * R_ROW : LY::ZROW;
         ro1 = ((base + dq - 1) % R_ROWS) * R_ROW;
         ro2 = ((base + dq) % R_ROWS) * R_ROW;
       }
@@ -265,7 +279,7 @@ __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
     f32x4 a0 = bA[0], a1 = bA[1];
     f32x2 acc[4];
     {
-      const float cbias = reinterpret_cast<const float*>(smem + R_WC)[72];
+      const float cbias = reinterpret_cast<const float*>(smem + LY::WC)[72];
 #pragma unroll
       for (int o = 0; o < 4; ++o) acc[o] = f32x2{cbias, 0.f};
     }
@@ -310,6 +324,7 @@ __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
     };
     auto window_row = [&](auto DY, const int ro) {
       constexpr int dy = decltype(DY)::value;
+      if (X3 && ro < 0) return;           // a row outside the image (wave-uniform): nothing to add
       const char* rowp = smem + ro;
       f32x4 lo[6], hi[6];                 // window columns X0 - 1 .. X0 + 4 of this row
 #pragma unroll
@@ -390,14 +405,31 @@ __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
     // matrix work of the next (independent) one ----
     a0 = swish_l2e(a0); a1 = swish_l2e(a1);
     f32x4 b[2][2];
+    if (X3) {
+      // the second layer the same way: its B operand is the 8 activations a lane holds (k index 8 kg + j <-> channel 4 kg + j for
+      // j < 4, 16 + 4 kg + j - 4 above: the host packs the weight planes in that order), K = 32 = one k-step, six MFMAs per tap
+      u32x4 yh, ym, yl;
+      split8_t32(a0, a1, yh, ym, yl);
 #pragma unroll
-    for (int ty2 = 0; ty2 < 2; ++ty2) {
-      b[ty2][0] = bB; b[ty2][1] = bB;
+      for (int ty2 = 0; ty2 < 2; ++ty2)
 #pragma unroll
-      for (int ks = 0; ks < 8; ++ks) {
-        const float bv = ks < 4 ? a0[ks & 3] : a1[ks & 3];
-        b[ty2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wB[((2 * ty2) * 8 + ks) * 64], bv, b[ty2][0], 0, 0, 0);
-        b[ty2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wB[((2 * ty2 + 1) * 8 + ks) * 64], bv, b[ty2][1], 0, 0, 0);
+        for (int tx2 = 0; tx2 < 2; ++tx2) {
+          const u32x4 wh = wBx[((2 * ty2 + tx2) * 3 + 0) * 64], wm = wBx[((2 * ty2 + tx2) * 3 + 1) * 64], wl = wBx[((2 * ty2 + tx2) * 3 + 2) * 64];
+          f32x4 hh = bB, rr = {0.f, 0.f, 0.f, 0.f};
+          rr = mfma16bf(wm, ym, rr); rr = mfma16bf(wh, yl, rr); rr = mfma16bf(wl, yh, rr); rr = mfma16bf(wh, ym, rr); rr = mfma16bf(wm, yh, rr);
+          hh = mfma16bf(wh, yh, hh);
+          b[ty2][tx2] = hh + rr;
+        }
+    } else {
+#pragma unroll
+      for (int ty2 = 0; ty2 < 2; ++ty2) {
+        b[ty2][0] = bB; b[ty2][1] = bB;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+          const float bv = ks < 4 ? a0[ks & 3] : a1[ks & 3];
+          b[ty2][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wB[((2 * ty2) * 8 + ks) * 64], bv, b[ty2][0], 0, 0, 0);
+          b[ty2][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wB[((2 * ty2 + 1) * 8 + ks) * 64], bv, b[ty2][1], 0, 0, 0);
+        }
       }
     }
     const int st_sel = (px_ok && p_on) ? 0 : 1;   // lanes / rounds with nothing to store write a dump granule instead (no branch)
@@ -414,8 +446,8 @@ __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
           c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wC[(4 + i) * 64], bs[i], c1, 0, 0, 0);
         }
         c0 = swish_l2e(c0); c1 = swish_l2e(c1);
-        const int o_a = st_sel ? R_DUMP + lane * 16 : prow[2 * ty2] + p_off + 2 * tx2 * R_PLANE;
-        const int o_b = st_sel ? R_DUMP + lane * 16 : prow[2 * ty2 + 1] + p_off + 2 * tx2 * R_PLANE;
+        const int o_a = st_sel ? LY::DUMP + lane * 16 : prow[2 * ty2] + p_off + 2 * tx2 * R_PLANE;
+        const int o_b = st_sel ? LY::DUMP + lane * 16 : prow[2 * ty2 + 1] + p_off + 2 * tx2 * R_PLANE;
         *reinterpret_cast<f32x4*>(smem + o_a) = c0;
         *reinterpret_cast<f32x4*>(smem + o_b) = c1;
       }
@@ -447,11 +479,13 @@ hipError_t launch_tail32(const Tail32Params& p, int num_cus, hipStream_t s) {
                                 : (p.out_dtype == SRCFD_BF16 ? (p.w1x ? tail32<1, false, true> : tail32<1, false>) : (p.w1x ? tail32<2, false, true> : tail32<2, false>)));
   if (p.target && p.w1x) return hipErrorInvalidValue;
   if (p.target && (p.out_dtype != SRCFD_F32 || !p.sse_partial)) return hipErrorInvalidValue;
-  hipError_t e = lds_attr_once(reinterpret_cast<const void*>(fn), T32_LDS);
+  if ((p.w1x == nullptr) != (p.w2x == nullptr)) return hipErrorInvalidValue;
+  const int lds = p.w1x ? T32Lay<true>::LDS : T32_LDS;
+  hipError_t e = lds_attr_once(reinterpret_cast<const void*>(fn), lds);
   if (e != hipSuccess) return e;
   const int S = p.seg > 1 ? p.seg : 1;
   const int blocks = tail32_blocks(p.n, S, num_cus);
-  hipLaunchKernelGGL(fn, dim3(blocks), dim3(512), T32_LDS, s, p);
+  hipLaunchKernelGGL(fn, dim3(blocks), dim3(512), lds, s, p);
   return hipGetLastError();
 }
 
