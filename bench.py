@@ -337,7 +337,7 @@ class Job:
         if self.world > 1:
             self.dist.barrier()
 
-    def timed(self, step, steps, warmup, pre_ms=0.0):
+    def timed(self, step, steps, warmup, pre_ms=0.0, pre_steps=0):
         """`warmup` untimed + exactly `steps` timed calls of `step`, bracketed by barrier + synchronize on both
         sides; returns the MAX over ranks of the seconds the timed calls took.  `pre_ms` > 0: BEFORE the counted warm-up
         steps, untimed steps are issued until that much wall time has passed -- the first ~50 ms after an idle spell run ~10 %
@@ -345,6 +345,8 @@ class Job:
         inside it.  The counted steps and warm-up stay exactly as given.  self.last_rank_ms = (min, max) over ranks of the
         per-step time, so a straggler is visible in an N > 1 line."""
         torch = self.torch
+        for _ in range(pre_steps):    # steps that contain a collective are pre-warmed by COUNT: every rank must issue the same number
+            step()
         if pre_ms > 0:
             t_pre = time.perf_counter()
             while (time.perf_counter() - t_pre) * 1e3 < pre_ms:
@@ -496,7 +498,10 @@ class Job:
             tr.allreduce_sum_(t.grads)      # the step's only collective (RCCL when backend == nccl)
             t.apply_adam()
 
-        dt = self.timed(step, steps, warmup)
+        # like the SR legs, untimed steps first (the leg starts on a device that idled through the trainers' set-up; its 15 ms timed
+        # region would otherwise sit inside the clock ramp -- 0.549 vs 0.505 ms per step measured); by count, not by wall time: the
+        # step holds a collective.  Round 3's line had none
+        dt = self.timed(step, steps, warmup, pre_steps=100)
         ms = dt / steps * 1e3
         t.sse.zero_()
         t.forward_backward(x, y, gb)
@@ -508,7 +513,7 @@ class Job:
                f"all_reduce(sum) of {t.n_params} f32 per step, backend {self.backend}",
                "tflops_model": round(flops_per_sample * gb / (ms * 1e-3) / 1e12, 2),
                "frac_f32_mfma_peak": round(flops_per_sample * batch / (ms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4),
-               "ms_per_step_rank_min_max": list(self.last_rank_ms),
+               "ms_per_step_rank_min_max": list(self.last_rank_ms), "untimed_pre_warm_steps": 100,
                "loss_finite": bool(np.isfinite(loss))}
 
         # strong scaling: global batch 256, 256 / G samples per rank and optimiser step (sr-ae-conv.ipynb:c386-388 BATCH_SIZE scaled
@@ -529,7 +534,7 @@ class Job:
                     tr.allreduce_sum_(trn.grads)
                     trn.apply_adam()
 
-                sdt = self.timed(sstep, max(4, steps // 5), 2)
+                sdt = self.timed(sstep, max(4, steps // 5), 2, pre_steps=3)
                 sms = sdt / max(4, steps // 5) * 1e3
                 strong[name] = {"ms_per_step": round(sms, 4), "samples_per_s": round(GB / (sms * 1e-3), 1), "calls_per_step": calls, "call_batch": mb,
                                 "frac_f32_mfma_peak": round(flops_per_sample * per_rank / (sms * 1e-3) / 1e12 / PEAK_FP32_TFLOPS, 4),
