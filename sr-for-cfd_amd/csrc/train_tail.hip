@@ -8,19 +8,23 @@
 // Only the output conv looks across pixels, and only through dpred: a tile stages the 10x10 window of dpred around
 // each of its pixels' 8x8 blocks.
 //
-// Work split: a tile = 16 consecutive pixels of the 50x50 level (flattened over the batch); the four waves of a
-// workgroup take the four taps (ty1, tx1) of ConvT#2 for the same tile, so each wave owns a quarter of every pixel's
-// block.  All matrix work is v_mfma_f32_16x16x4_f32 (exact f32 products):
+// Work split: a tile = 16 consecutive pixels of the 50x50 level (flattened over the batch); four waves take the four
+// taps (ty1, tx1) of ConvT#2 for the same tile, so each wave owns a quarter of every pixel's block; a workgroup is
+// eight waves = two tile slots (the two waves of a SIMD work on different tiles).  All matrix work is
+// v_mfma_f32_16x16x4_f32 (exact f32 products):
 //   T form (rows = channels, columns = the 16 pixels; lane (n, g) register i = element (channel 4g + i, pixel n)):
 //     the forward chain and the data gradients, as in tail32 -- an accumulator is the B operand of the next product;
 //   P form (rows = pixels; lane (n, g) register i = element (pixel 4g + i, channel n)): both operands of a weight
 //     gradient dW[co][ci] = sum_px dZ[px][co] X[px][ci] (the pixel index is the MFMA's k).  T -> P is one 16-byte LDS
 //     store + four 4-byte loads per tile through a wave-private 16 x 20 float image (conflict-free both ways).
-// Weight gradients accumulate in registers over all tiles of the workgroup (ConvT#2: the wave's own tap, 32 registers;
+// The output conv's two gradients are banded (Toeplitz) MFMA products over the 3 x 4 dpred window that serves both
+// columns tx3 of a row pair (on the vector unit they cost 576 FMAs per item and 72 more registers per lane).
+// Weight gradients accumulate in registers over all tiles of a wave (ConvT#2: the wave's own tap, 32 registers;
 // ConvT#3 / #4 / output conv / biases: partial sums per wave), are summed over lanes and waves in a fixed order at the
 // end and leave as ONE slab per workgroup in flat-parameter order; train.hip's wgrad_finish_all adds the slabs.  No
 // float atomics: gradients are bit-identical run to run.
-// The data gradient of ConvT#2's input sums over the four taps = the four waves: through LDS, then x swish'(Z1) and out.
+// The data gradient of ConvT#2's input sums over the four taps = the four waves of a slot: through LDS, then
+// x swish'(Z1) and out.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
