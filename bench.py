@@ -51,7 +51,7 @@ PEAK_BF16_TFLOPS = 2500.0         # MI355X dense bf16/f16 MFMA (MI355X_MICROARCH
 PEAK_FP32_TFLOPS = 157.3          # f32-input MFMA
 PEAK_HBM_GBS = 8000.0
 PRE_WARM_MS = 120.0               # untimed steps by wall time in front of the counted warm-up of an SR leg (clock ramp; Job.timed)
-REFUSED_ENV = ("SRCFD_TAIL_ABLATE", "SRCFD_MID_ABLATE", "SRCFD_TAIL_PROF")   # switch work off / add syncs: never a headline
+REFUSED_ENV = ("SRCFD_TAIL_ABLATE", "SRCFD_MID_ABLATE", "SRCFD_TAIL_PROF", "SRCFD_TAIL32_ABLATE")   # switch work off / add syncs: never a headline
 # A/B switches: each selects a complete second implementation of a stage (results stay right), but a line measured under one is
 # not the shipped path: refused like the diagnostic switches (SRCFD_BENCH_ALLOW_DIAG=1 marks the line INVALID instead)
 AB_ENV_OFF_WHEN_ZERO = ("SRCFD_ENC", "SRCFD_DENSE1")
@@ -493,10 +493,9 @@ class Job:
         gb = batch * self.world
 
         def step():
-            t.grads.zero_()
-            t.forward_backward(x, y, gb)
-            tr.allreduce_sum_(t.grads)      # the step's only collective (RCCL when backend == nccl)
-            t.apply_adam()
+            # the product's own optimisation step (train.py Trainer.step): forward + backward storing the gradients (no zero-fill
+            # launches), the flat all-reduce -- the step's only collective, RCCL when backend == nccl -- and Adam; no loss read-back
+            t.step(x, y, gb, return_loss=False)
 
         # like the SR legs, untimed steps first (the leg starts on a device that idled through the trainers' set-up; its 15 ms timed
         # region would otherwise sit inside the clock ramp -- 0.549 vs 0.505 ms per step measured); by count, not by wall time: the
@@ -527,10 +526,9 @@ class Job:
                 calls = per_rank // mb
 
                 def sstep(trn=trn, mb=mb, calls=calls):
-                    trn.grads.zero_()
-                    for c in range(calls):
+                    for c in range(calls):     # the first call of a step stores the gradients, the others add to them
                         lo = (c * mb) % 32
-                        trn.forward_backward(x32[lo:lo + mb], y32[lo:lo + mb], GB)
+                        trn.forward_backward(x32[lo:lo + mb], y32[lo:lo + mb], GB, overwrite=(c == 0))
                     tr.allreduce_sum_(trn.grads)
                     trn.apply_adam()
 

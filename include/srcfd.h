@@ -312,12 +312,18 @@ int srcfd_trainer_get_params(const srcfd_trainer* t, float* params_host);
 /* Forward + backward on n <= max_batch samples: x_dev (n,h,w,c) inputs, y_dev targets of the model's
  * output shape.  ADDS d/dparams of loss_scale * sum((pred - y)^2) into grads_dev (zero it first; pass
  * loss_scale = 1 / (global batch * output elements) for Keras' reduce_mean(mse)) and adds the local sum of
- * squared errors to *sse_dev (device double, may be NULL).  Enqueues on hip_stream, no synchronisation: the weight
- * gradients run on a stream of the trainer's own that forks from and joins hip_stream inside the call.  From the second
+ * squared errors to *sse_dev (device double, may be NULL).  Enqueues on hip_stream, no synchronisation: part of the weight
+ * gradients runs on a stream of the trainer's own that forks from and joins hip_stream inside the call.  From the second
  * call with the same params_dev / grads_dev / sse_dev / n / loss_scale the step is replayed as one hipGraph (x_dev and
  * y_dev are first copied to staging buffers, so they need not stay at one address). */
 int srcfd_trainer_forward_backward(srcfd_trainer* t, const float* params_dev, const float* x_dev, const float* y_dev, int n,
                                    float loss_scale, float* grads_dev, double* sse_dev, void* hip_stream);
+/* The same with flags.  SRCFD_TRAIN_OVERWRITE: grads_dev and *sse_dev are WRITTEN, not added into (every parameter's gradient is
+ * stored by exactly one thread of the step's last launch): a step needs no zero-fill launches in front of it.  Without the flag
+ * this is srcfd_trainer_forward_backward (accumulation over several calls, e.g. micro-batches of one optimiser step). */
+#define SRCFD_TRAIN_OVERWRITE 1
+int srcfd_trainer_forward_backward_ex(srcfd_trainer* t, const float* params_dev, const float* x_dev, const float* y_dev, int n,
+                                      float loss_scale, float* grads_dev, double* sse_dev, int flags, void* hip_stream);
 /* Keras Adam update, step counted from 1: alpha_t = lr*sqrt(1-beta2^t)/(1-beta1^t); p -= alpha_t*m/(sqrt(v)+eps). */
 int srcfd_adam_step(float* params_dev, const float* grads_dev, float* m_dev, float* v_dev, int64_t n, int step, float lr,
                     float beta1, float beta2, float eps, void* hip_stream);

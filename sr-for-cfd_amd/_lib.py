@@ -15,6 +15,7 @@ OK, ENOENT, EIO, ENOMEM, ENODEV, EINVAL, EKEY, EHIP = 0, -2, -5, -12, -19, -22, 
 
 F32, F64, I32, I64, U8, STR, BF16, F16 = 0, 1, 2, 3, 4, 5, 16, 17
 PREC_FP32, PREC_BF16, PREC_FP32_NAIVE, PREC_F16, PREC_FP32X3 = 0, 1, 2, 3, 4
+TRAIN_OVERWRITE = 1   # srcfd_trainer_forward_backward_ex: grads and sse are written, not added into
 LAYER_CONV2D, LAYER_CONV2D_TRANSPOSE, LAYER_DENSE, LAYER_FLATTEN, LAYER_RESHAPE = 1, 2, 3, 4, 5
 ACT_LINEAR, ACT_SWISH, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
 FLAG_NAN_GUARD = 1
@@ -117,6 +118,7 @@ _protos = {
     "srcfd_trainer_num_params": (C.c_int64, [_p]),
     "srcfd_trainer_get_params": (C.c_int, [_p, _p]),
     "srcfd_trainer_forward_backward": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_float, _p, _p, _p]),
+    "srcfd_trainer_forward_backward_ex": (C.c_int, [_p, _p, _p, _p, C.c_int, C.c_float, _p, _p, C.c_int, _p]),
     "srcfd_model_save_superres_h5": (C.c_int, [_p, C.c_char_p]),
     "srcfd_model_load_superres_h5": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(_p)]),
     "srcfd_prepare_inputs_device": (C.c_int, [_p, C.c_int, C.c_int, C.c_int, _p, _p, C.c_int, _p, C.c_int, C.c_double, _p, _p, _p]),

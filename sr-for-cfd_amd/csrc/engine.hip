@@ -554,6 +554,9 @@ int Model::forward_generic(const float* x_dev, int n, const float* aff_in, const
         tp.w1x = d_pack_x3 + t32_w1x;
         tp.w2x = d_pack_x3 + t32_w2x;
       }
+#ifdef SRCFD_DIAG
+      { static const int abl = [] { const char* e = getenv("SRCFD_TAIL32_ABLATE"); return e ? atoi(e) : 0; }(); tp.ablate = abl; }
+#endif
       const std::string nm = op.name + "+" + ops[i + 1].name + "+" + ops[i + 2].name + "+" + ops[i + 3].name + (tp.w1x ? "(x3)" : "");
       return launch(nm.c_str(), s, [&] { return launch_tail32(tp, num_cus, s); });
     }

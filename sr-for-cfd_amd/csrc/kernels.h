@@ -127,6 +127,9 @@ struct Tail32Params {
   // ... and the second layer's (unscaled, like w2f): [tap2 4][plane 3][64 lanes] x 16 B, lane (m, kg) element j =
   // plane(W2[tap2][co m][ci j < 4 ? 4 kg + j : 16 + 4 kg + j - 4]) -- the k order of the first layer's accumulators.  Both or neither.
   const uint16_t* w2x = nullptr;
+  // diagnostic (SRCFD_TAIL32_ABLATE, -DSRCFD_DIAG builds only): 1 no swish, 2 no output conv arithmetic, 4 no third-layer MFMAs,
+  // 8 no first / second layer MFMAs, 16 no operand splits (X3), 32 no ring stores, 64 no window reads
+  int ablate = 0;
 };
 hipError_t launch_tail32(const Tail32Params& p, int num_cus, hipStream_t s);
 int tail32_segments(int n, int H, int num_cus);

@@ -129,6 +129,13 @@ __device__ __forceinline__ void split8_t32(const f32x4& v0, const f32x4& v1, u32
   }
 }
 
+// Diagnostic work-skipping switches (Tail32Params::ablate) exist only in a -DSRCFD_DIAG build (make DIAG=1).
+#ifdef SRCFD_DIAG
+#define T32_ABL(bit) (p.ablate & (bit))
+#else
+#define T32_ABL(bit) 0
+#endif
+
 template <int OUT, bool TRAIN, bool X3 = false>  // OUT: 0 f32, 1 bf16, 2 f16
 __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -301,12 +308,18 @@ __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int c = 0; c < 2; ++c) wL[t][c] = w1x[((((ty1r * 2 + tx1) * 2 + t) * 2 + c) * 3 + 2) * 64];
+      if (T32_ABL(16)) {
+        xh[0] = __builtin_bit_cast(u32x4, xs[0]); xm[0] = __builtin_bit_cast(u32x4, xs[1]); xl[0] = xh[0];
+        xh[1] = __builtin_bit_cast(u32x4, xs[2]); xm[1] = __builtin_bit_cast(u32x4, xs[3]); xl[1] = xh[1];
+      } else {
       split8_t32(xs[0], xs[1], xh[0], xm[0], xl[0]);
       split8_t32(xs[2], xs[3], xh[1], xm[1], xl[1]);
+      }
     }
     auto layer1x = [&](auto TY1, auto PART) {   // PART 0: mid x mid, hi x lo; 1: hi x mid, mid x hi, hi x hi; 2: lo x hi (the late plane), sets meet
       constexpr int ty1 = decltype(TY1)::value;
       constexpr int part = decltype(PART)::value;
+      if (T32_ABL(8)) { if (part == 2) { a0 = a0 + __builtin_bit_cast(f32x4, xh[0]); a1 = a1 + __builtin_bit_cast(f32x4, xm[1]) + __builtin_bit_cast(f32x4, xl[0]); } return; }
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         if (part == 0) {
@@ -325,6 +338,7 @@ __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
     auto window_row = [&](auto DY, const int ro) {
       constexpr int dy = decltype(DY)::value;
       if (X3 && ro < 0) return;           // a row outside the image (wave-uniform): nothing to add
+      if (T32_ABL(64)) return;
       const char* rowp = smem + ro;
       f32x4 lo[6], hi[6];                 // window columns X0 - 1 .. X0 + 4 of this row
 #pragma unroll
@@ -333,6 +347,10 @@ __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
         lo[j] = *reinterpret_cast<const f32x4*>(gp);
         hi[j] = *reinterpret_cast<const f32x4*>(gp + R_HALF);
       }
+      if (T32_ABL(2)) {   // keep the reads alive: one add per granule
+#pragma unroll
+        for (int j = 0; j < 6; ++j) acc[j & 3] = acc[j & 3] + f32x2{lo[j][0], hi[j][3]};
+      } else
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
         const f32x4 wl = wk[(dy * 3 + dx) * 2], wh = wk[(dy * 3 + dx) * 2 + 1];
@@ -403,19 +421,21 @@ __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
     }
     // ---- the rest of the chain: second layer (both tap rows), third layer; the activation of one tile runs beside the
     // matrix work of the next (independent) one ----
-    a0 = swish_l2e(a0); a1 = swish_l2e(a1);
+    if (!T32_ABL(1)) { a0 = swish_l2e(a0); a1 = swish_l2e(a1); }
     f32x4 b[2][2];
     if (X3) {
       // the second layer the same way: its B operand is the 8 activations a lane holds (k index 8 kg + j <-> channel 4 kg + j for
       // j < 4, 16 + 4 kg + j - 4 above: the host packs the weight planes in that order), K = 32 = one k-step, six MFMAs per tap
       u32x4 yh, ym, yl;
-      split8_t32(a0, a1, yh, ym, yl);
+      if (T32_ABL(16)) { yh = __builtin_bit_cast(u32x4, a0); ym = __builtin_bit_cast(u32x4, a1); yl = yh; }
+      else split8_t32(a0, a1, yh, ym, yl);
 #pragma unroll
       for (int ty2 = 0; ty2 < 2; ++ty2)
 #pragma unroll
         for (int tx2 = 0; tx2 < 2; ++tx2) {
           const u32x4 wh = wBx[((2 * ty2 + tx2) * 3 + 0) * 64], wm = wBx[((2 * ty2 + tx2) * 3 + 1) * 64], wl = wBx[((2 * ty2 + tx2) * 3 + 2) * 64];
           f32x4 hh = bB, rr = {0.f, 0.f, 0.f, 0.f};
+          if (T32_ABL(8)) { b[ty2][tx2] = hh + __builtin_bit_cast(f32x4, yh) + __builtin_bit_cast(f32x4, ym) + __builtin_bit_cast(f32x4, yl) + __builtin_bit_cast(f32x4, wh); continue; }
           rr = mfma16bf(wm, ym, rr); rr = mfma16bf(wh, yl, rr); rr = mfma16bf(wl, yh, rr); rr = mfma16bf(wh, ym, rr); rr = mfma16bf(wm, yh, rr);
           hh = mfma16bf(wh, yh, hh);
           b[ty2][tx2] = hh + rr;
@@ -435,21 +455,25 @@ __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
     const int st_sel = (px_ok && p_on) ? 0 : 1;   // lanes / rounds with nothing to store write a dump granule instead (no branch)
 #pragma unroll
     for (int ty2 = 0; ty2 < 2; ++ty2) {
-      b[ty2][0] = swish_l2e(b[ty2][0]); b[ty2][1] = swish_l2e(b[ty2][1]);
+      if (!T32_ABL(1)) { b[ty2][0] = swish_l2e(b[ty2][0]); b[ty2][1] = swish_l2e(b[ty2][1]); }
 #pragma unroll
       for (int tx2 = 0; tx2 < 2; ++tx2) {
         const f32x4 bs = b[ty2][tx2];
         f32x4 c0 = bC, c1 = bC;
+        if (T32_ABL(4)) { c0 = c0 + bs; c1 = c1 - bs; } else
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wC[i * 64], bs[i], c0, 0, 0, 0);
           c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wC[(4 + i) * 64], bs[i], c1, 0, 0, 0);
         }
-        c0 = swish_l2e(c0); c1 = swish_l2e(c1);
+        if (!T32_ABL(1)) { c0 = swish_l2e(c0); c1 = swish_l2e(c1); }
         const int o_a = st_sel ? LY::DUMP + lane * 16 : prow[2 * ty2] + p_off + 2 * tx2 * R_PLANE;
         const int o_b = st_sel ? LY::DUMP + lane * 16 : prow[2 * ty2 + 1] + p_off + 2 * tx2 * R_PLANE;
+        if (T32_ABL(32)) { if (c0[0] + c1[1] == 123.456f) *reinterpret_cast<f32x4*>(smem + o_a) = c0; }
+        else {
         *reinterpret_cast<f32x4*>(smem + o_a) = c0;
         *reinterpret_cast<f32x4*>(smem + o_b) = c1;
+        }
       }
     }
 

@@ -74,7 +74,7 @@ __global__ void __launch_bounds__(256) mse_grad_f32(const float* __restrict__ pr
   if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
 }
 
-__global__ void __launch_bounds__(256) sum_partials_f64(const double* __restrict__ partial, int n, double* __restrict__ out) {
+__global__ void __launch_bounds__(256) sum_partials_f64(const double* __restrict__ partial, int n, double* __restrict__ out, int overwrite) {
   __shared__ double red[256];
   double acc = 0.0;
   for (int i = threadIdx.x; i < n; i += 256) acc += partial[i];
@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(256) sum_partials_f64(const double* __restrict
     if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
     __syncthreads();
   }
-  if (threadIdx.x == 0) *out += red[0];
+  if (threadIdx.x == 0) *out = overwrite ? red[0] : *out + red[0];
 }
 
 // dst[i] = map[i] > 0 ? src[map[i]-1] : 0   (flat params -> packed operand buffers); slots from scale_begin on carry a factor
@@ -384,12 +384,17 @@ static void launch_wgrad(const GemmDesc& d, const WgradPlan& p, const float* X, 
 // One launch sums the slabs of ALL ops of a step (every op keeps its slabs in space of its own until then): as fourteen
 // launches of 2-26 us these sums were 150 us of the weight-gradient stream's 395 us, and that stream was the step's critical
 // path.  The table travels as a kernel argument (it depends on the batch size through the slab counts).
+// Ops of one layer (the output phases of a strided transposed convolution) own disjoint kernel taps but share the layer's bias:
+// the first op of the layer sums the bias rows of the others after its own (`extra`, fixed order), the others skip theirs
+// (`bias_skip`) -- every parameter is written by exactly one thread of one launch (round 3 ran one launch per phase ordinal, the
+// later ones adding into the first one's biases: three more launches of 5 us at the end of every step).
 struct FinishOp {
   const float* part; const int* map; int64_t elems;
   int nslices, K, N, Npad, CO, groups, block0;   // block0: first workgroup of this op in the merged grid
+  int bias_skip, nextra, extra[3];               // extra: table indices of the layer's other ops
 };
 constexpr int MAX_FINISH_OPS = 24;
-struct FinishTable { FinishOp op[MAX_FINISH_OPS]; int nops; };
+struct FinishTable { FinishOp op[MAX_FINISH_OPS]; int nops; int overwrite; };   // overwrite: grads = sum instead of grads += sum
 
 __global__ void __launch_bounds__(256) wgrad_finish_all_f32(const FinishTable tab, float* __restrict__ grads) {
   int oi = 0;
@@ -401,7 +406,8 @@ __global__ void __launch_bounds__(256) wgrad_finish_all_f32(const FinishTable ta
   const int nslices = o.nslices, K = o.K, N = o.N, Npad = o.Npad, CO = o.CO, groups = o.groups;
   const int blk = (int)blockIdx.x - o.block0;
   // (256 / groups) consecutive elements x `groups` slab groups per block; group g adds slabs g, g+groups, ...
-  // (four independent chains so the loads overlap); the groups are then added in order.
+  // (four independent chains so the loads overlap); the groups are then added in order.  (~85 MB of slabs, maps and gradients in
+  // 30 us at batch 8.  Four elements per thread -- consecutive with 16-byte loads, or strided -- were measured: 44 / 33 us.)
   __shared__ float red[256];
   const int epb = 256 / groups, e = threadIdx.x % epb, g = threadIdx.x / epb;
   const int64_t i = (int64_t)blk * epb + e;
@@ -412,10 +418,17 @@ __global__ void __launch_bounds__(256) wgrad_finish_all_f32(const FinishTable ta
     const int row = (int)(i / Npad), col = (int)(i - (int64_t)row * Npad);
     if (k > 0) {
       if (row == K) {
-        if (col >= CO) k = 0;
-        else
+        if (col >= CO || o.bias_skip) k = 0;
+        else {
           for (int z = g; z < nslices; z += groups)
             for (int c = col; c < N; c += CO) s += part[(int64_t)z * elems + (int64_t)row * Npad + c];
+          for (int x = 0; x < o.nextra; ++x) {
+            const FinishOp& eo = tab.op[o.extra[x]];
+            const float* __restrict__ ep = eo.part + (int64_t)eo.K * eo.Npad;
+            for (int z = g; z < eo.nslices; z += groups)
+              for (int c = col; c < eo.N; c += eo.CO) s += ep[(int64_t)z * eo.elems + c];
+          }
+        }
       } else {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int z = g;
@@ -435,7 +448,7 @@ __global__ void __launch_bounds__(256) wgrad_finish_all_f32(const FinishTable ta
   if (g == 0 && k > 0) {
     float tot = red[e];
     for (int q = 1; q < groups; ++q) tot += red[q * epb + e];
-    grads[k - 1] += tot;
+    grads[k - 1] = tab.overwrite ? tot : grads[k - 1] + tot;
   }
 }
 
@@ -476,34 +489,41 @@ struct Trainer {
   int64_t n_params = 0;
   std::vector<float> init_params;
   // device
+  // ONE packed operand buffer, gathered from the flat parameters by ONE launch at the head of a step:
+  // [forward operands | data-gradient operands | the fused tail's operands (scaled slots)]
   float* d_pack = nullptr; int* d_pack_map = nullptr; size_t pack_elems = 0;
-  float* d_dpack = nullptr; int* d_dpack_map = nullptr; size_t dpack_elems = 0;
+  float* d_dpack = nullptr; size_t dpack_off = 0, dpack_elems = 0;   // d_dpack = d_pack + dpack_off
   float* d_zero_bias = nullptr; size_t zero_bias_elems = 0;
   std::vector<float*> Z, Y;       // per compute layer (Y aliases Z for linear layers)
-  // dZ buffers of the data-gradient chain: a ring of three (the chain may run two layers ahead of the weight gradients before it
-  // has to wait for one), sized by the largest activation the chain sees; with the fused tail one more slot holds dpred.
-  // (Measured and not kept, round 4: one slot per layer, so that the main stream never waits for the weight-gradient stream --
-  // the replayed graph then spreads over three hardware queues and the step gets SLOWER, 0.531 vs 0.508 ms at batch 8: what costs
-  // ~10 us is every fan-out edge of the graph, not the wait; tools/prof_train_step.sh.  SRCFD_TRAIN_RING=n to repeat it.)
-  std::vector<float*> dbuf;
-  int ring = 3;
-  // The weight gradients of a layer (wgrad + finish) depend only on its dZ and on the forward activations, not on the
-  // data-gradient chain, so they run on a second stream beside it (at micro-batch sizes no kernel fills the chip).
+  // dZ of every layer has a buffer of its own (dz[li], n x out_elems), + dpred with the fused tail: nothing in the backward
+  // pass ever waits for a buffer to be free.
+  std::vector<float*> dz;
+  float* d_dpred = nullptr;
+  // The weight gradients of a layer depend only on its dZ and on the forward activations, not on the data-gradient chain.
+  // In a replayed hipGraph every node with two successors costs ~10 us before EITHER successor starts (tools/prof_train_step.sh:
+  // the data-gradient GEMM and the weight gradient of a layer started together, 9-11 us after their common predecessor), so
+  // forking the weight gradients off layer by layer (rounds 2-3, ring of three dZ buffers) put eight such gaps on the
+  // data-gradient chain.  Now ONE fork: the weight gradients of the layers >= aux_from (default: the four layers in front of the
+  // fused tail -- ConvT#1, ConvT#0, dense_1, latent_vector: 80 % of the weight-gradient time) go to the second stream as soon as
+  // dZ of layer aux_from exists; the chain runs on without another fork, the remaining layers' weight gradients follow it on the
+  // main stream, the two streams join once in front of the slab sums.  SRCFD_TRAIN_AUX_FROM=n moves the split (n >= number of
+  // layers: one stream); measured at batch 8 / 16 / 32 (ms per step): n = 2: 0.463 / 0.606 / 0.863, 3: 0.447 / 0.586 / 0.833,
+  // 4: 0.459 / 0.592 / 0.831, 5: 0.466 / - / 0.854, 6: 0.510 / - / 0.913; the per-layer forks of round 3: 0.503 / - / 0.90.
   hipStream_t aux = nullptr;
-  std::vector<hipEvent_t> ev_dz, ev_wg;            // per layer: dZ ready (main stream) / weight gradient done (aux)
+  int aux_from = -1;
+  hipEvent_t ev_fork = nullptr;
   // (A third stream for the slab sums was tried: two forked streams that wait on each other send hipStreamEndCapture into an
   // endless recursion on ROCm 7.2, and with one-way dependencies the three-branch graph replayed level by level, 0.83 ms
   // against 0.72 for two branches.  The sums are ONE launch at the end of the aux stream instead: wgrad_finish_all_f32.)
   hipEvent_t ev_fin = nullptr;                     // end of the aux stream's work of the step
-  hipEvent_t ev_start = nullptr, ev_dpack = nullptr;   // the data-gradient operands are packed on the aux stream beside the forward pass
   bool overlap = true;                             // SRCFD_TRAIN_OVERLAP=0: everything on the caller's stream
   // A step is ~100 launches and event operations of 5-40 us kernels: issued one by one the host cannot keep the device
   // fed (20 % of the step was idle gaps).  The second time a step with the same buffers and batch size is asked for it is
   // captured (both streams: the aux branch forks and joins inside the capture) and replayed as one hipGraph launch.
   // x and y go through staging buffers so that the graph's pointers never change.
   struct StepKey {
-    const float* params = nullptr; float* grads = nullptr; double* sse = nullptr; int n = 0; float loss_scale = 0.f;
-    bool operator==(const StepKey& o) const { return params == o.params && grads == o.grads && sse == o.sse && n == o.n && loss_scale == o.loss_scale; }
+    const float* params = nullptr; float* grads = nullptr; double* sse = nullptr; int n = 0, flags = 0; float loss_scale = 0.f;
+    bool operator==(const StepKey& o) const { return params == o.params && grads == o.grads && sse == o.sse && n == o.n && flags == o.flags && loss_scale == o.loss_scale; }
   };
   struct StepGraph { StepKey key; int seen = 0; hipGraphExec_t exec = nullptr; };
   std::vector<StepGraph> graphs;                   // at most 8 keys (full batches, the ragged last batch, ...)
@@ -531,14 +551,11 @@ Trainer::~Trainer() {
   if (cap_stream) (void)hipStreamDestroy(cap_stream);
   if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); }
   if (ev_fin) (void)hipEventDestroy(ev_fin);
-  if (ev_start) (void)hipEventDestroy(ev_start);
-  if (ev_dpack) (void)hipEventDestroy(ev_dpack);
+  if (ev_fork) (void)hipEventDestroy(ev_fork);
   if (d_xs) (void)hipFree(d_xs);
   if (d_ys) (void)hipFree(d_ys);
-  for (hipEvent_t e : ev_dz) (void)hipEventDestroy(e);
-  for (hipEvent_t e : ev_wg) (void)hipEventDestroy(e);
-  for (float* b : dbuf) if (b) (void)hipFree(b);
-  for (void* p : {(void*)d_pack, (void*)d_pack_map, (void*)d_dpack, (void*)d_dpack_map, (void*)d_zero_bias, (void*)d_part, (void*)d_loss_partial, (void*)d_splitk, (void*)d_pack_scale, (void*)d_tail_slabs,
+  for (float* b : dz) if (b) (void)hipFree(b);
+  for (void* p : {(void*)d_pack, (void*)d_pack_map, (void*)d_dpred, (void*)d_zero_bias, (void*)d_part, (void*)d_loss_partial, (void*)d_splitk, (void*)d_pack_scale, (void*)d_tail_slabs,
                   (void*)d_tail_gmap})
     if (p) (void)hipFree(p);
   for (size_t i = 0; i < Z.size(); ++i) {
@@ -657,9 +674,7 @@ static int trainer_build(Trainer& t, const Model& model, int max_batch) {
     t.use_tail = t.tail.ok && !(e && atoi(e) == 0) && (uint64_t)max_batch * t.tail.H * t.tail.W * t.tail.H * t.tail.W < (1ull << 32);
   }
   while (ipack.size() % 64) ipack.push_back(0.f);
-  t.tail_pack_off = ipack.size();
   if (t.use_tail) {
-    for (int k : t.tail.map) ipack.push_back((float)k);
     HIPCHECK(hipMalloc(&t.d_pack_scale, t.tail.scale.size() * sizeof(float)));
     HIPCHECK(hipMemcpy(t.d_pack_scale, t.tail.scale.data(), t.tail.scale.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHECK(hipMalloc(&t.d_tail_slabs, (size_t)t.num_cus * TT_PARAMS * sizeof(float)));
@@ -668,11 +683,6 @@ static int trainer_build(Trainer& t, const Model& model, int max_batch) {
     HIPCHECK(hipMalloc(&t.d_tail_gmap, TT_PARAMS * sizeof(int)));
     HIPCHECK(hipMemcpy(t.d_tail_gmap, gm.data(), TT_PARAMS * sizeof(int), hipMemcpyHostToDevice));
   }
-  while (ipack.size() % 64) ipack.push_back(0.f);
-  t.pack_elems = ipack.size();
-  int rc = upload_map(ipack, &t.d_pack_map);
-  if (rc) return rc;
-  HIPCHECK(hipMalloc(&t.d_pack, t.pack_elems * sizeof(float)));
   size_t part_need = 0;   // every op has slab space of its own: the sum of one op never has to finish before the next op's slabs are written
   for (const Op& op : iops) {
     TrainOp to;
@@ -708,10 +718,17 @@ static int trainer_build(Trainer& t, const Model& model, int max_batch) {
   std::vector<float> dpack;
   build_dgrad(im, t.layers, t.dops, dpack);
   while (!dpack.empty() && dpack.size() % 64) dpack.push_back(0.f);
+  t.dpack_off = ipack.size();
   t.dpack_elems = dpack.size();
-  rc = upload_map(dpack, &t.d_dpack_map);
+  ipack.insert(ipack.end(), dpack.begin(), dpack.end());
+  t.tail_pack_off = ipack.size();            // the scaled slots come last (gather_pack_f32: one scale region)
+  if (t.use_tail) for (int k : t.tail.map) ipack.push_back((float)k);
+  while (ipack.size() % 64) ipack.push_back(0.f);
+  t.pack_elems = ipack.size();
+  int rc = upload_map(ipack, &t.d_pack_map);
   if (rc) return rc;
-  HIPCHECK(hipMalloc(&t.d_dpack, std::max<size_t>(t.dpack_elems, 1) * sizeof(float)));
+  HIPCHECK(hipMalloc(&t.d_pack, t.pack_elems * sizeof(float)));
+  t.d_dpack = t.d_pack + t.dpack_off;
   int maxn = 32;
   for (auto& o : t.dops) maxn = std::max(maxn, o.d.Npad);
   t.zero_bias_elems = maxn;
@@ -728,16 +745,14 @@ static int trainer_build(Trainer& t, const Model& model, int max_batch) {
     t.Z.push_back(z);
     t.Y.push_back(y);
   }
-  if (t.use_tail) {
-    size_t me = t.layers.back().out_elems;   // dpred
-    for (int li = 0; li < t.tail.first_layer; ++li) me = std::max(me, t.layers[li].out_elems);
-    { const char* e = getenv("SRCFD_TRAIN_RING"); t.ring = e && atoi(e) >= 3 ? std::min(atoi(e), 16) : 3; }
-    t.dbuf.assign(t.ring + 1, nullptr);      // + the slot of dpred
-    for (auto*& b : t.dbuf) HIPCHECK(hipMalloc(&b, (size_t)max_batch * me * sizeof(float)));
-  } else {
-    t.ring = 3;
-    t.dbuf.assign(3, nullptr);
-    for (auto*& b : t.dbuf) HIPCHECK(hipMalloc(&b, (size_t)max_batch * maxe * sizeof(float)));
+  (void)maxe;
+  {
+    const int Lg = t.use_tail ? t.tail.first_layer : (int)t.layers.size();
+    t.dz.assign(Lg, nullptr);
+    for (int li = 0; li < Lg; ++li) HIPCHECK(hipMalloc(&t.dz[li], (size_t)max_batch * t.layers[li].out_elems * sizeof(float)));
+    if (t.use_tail) HIPCHECK(hipMalloc(&t.d_dpred, (size_t)max_batch * t.layers.back().out_elems * sizeof(float)));
+    const char* e = getenv("SRCFD_TRAIN_AUX_FROM");
+    t.aux_from = e ? std::max(atoi(e), 0) : std::max(Lg - 4, 0);
   }
   { const char* e = getenv("SRCFD_TRAIN_OVERLAP"); t.overlap = !(e && atoi(e) == 0); }
   { const char* e = getenv("SRCFD_TRAIN_GRAPH"); t.use_graph = !(e && atoi(e) == 0); }
@@ -751,15 +766,7 @@ static int trainer_build(Trainer& t, const Model& model, int max_batch) {
   if (t.overlap) {
     HIPCHECK(hipStreamCreateWithFlags(&t.aux, hipStreamNonBlocking));
     HIPCHECK(hipEventCreateWithFlags(&t.ev_fin, hipEventDisableTiming));
-    HIPCHECK(hipEventCreateWithFlags(&t.ev_start, hipEventDisableTiming));
-    HIPCHECK(hipEventCreateWithFlags(&t.ev_dpack, hipEventDisableTiming));
-    for (size_t i = 0; i < t.layers.size(); ++i) {
-      hipEvent_t a, b;
-      HIPCHECK(hipEventCreateWithFlags(&a, hipEventDisableTiming));
-      t.ev_dz.push_back(a);
-      HIPCHECK(hipEventCreateWithFlags(&b, hipEventDisableTiming));
-      t.ev_wg.push_back(b);
-    }
+    HIPCHECK(hipEventCreateWithFlags(&t.ev_fork, hipEventDisableTiming));
   }
   HIPCHECK(hipMalloc(&t.d_loss_partial, 1024 * sizeof(double)));
   size_t sk = 0;
@@ -780,23 +787,15 @@ static int trainer_build(Trainer& t, const Model& model, int max_batch) {
 }
 
 static int trainer_step(Trainer& t, const float* params, const float* x, const float* y, int n, float loss_scale, float* grads, double* sse_dev,
-                        hipStream_t s) {
+                        int flags, hipStream_t s) {
   if (n <= 0 || n > t.max_batch) { set_error("training: batch outside [1, max_batch]"); return SRCFD_EINVAL; }
   HIPCHECK(hipSetDevice(t.device));
+  const int overwrite = (flags & SRCFD_TRAIN_OVERWRITE) ? 1 : 0;
   auto grid = [](int64_t n_) { return dim3((unsigned)((n_ + 255) / 256)); };
-  // 1. pack operands from the flat parameters
+  // 1. pack every operand of the step from the flat parameters: one launch (the data-gradient operands used to be packed on the
+  //    second stream beside the forward pass -- a fork and a join of the replayed graph, ~10 us each, to hide a 12 us kernel)
   hipLaunchKernelGGL(gather_pack_f32, grid(t.pack_elems / 4), dim3(256), 0, s, params, t.d_pack_map, t.d_pack, (int64_t)t.pack_elems,
                      (const float*)t.d_pack_scale, (int64_t)(t.use_tail ? t.tail_pack_off : t.pack_elems));
-  // the data-gradient operands are not needed before the backward pass: packed on the aux stream, beside the forward pass
-  if (t.dpack_elems) {
-    if (t.overlap) {
-      HIPCHECK(hipEventRecord(t.ev_start, s));
-      HIPCHECK(hipStreamWaitEvent(t.aux, t.ev_start, 0));
-    }
-    hipLaunchKernelGGL(gather_pack_f32, grid(t.dpack_elems / 4), dim3(256), 0, t.overlap ? t.aux : s, params, t.d_dpack_map, t.d_dpack,
-                       (int64_t)t.dpack_elems, (const float*)nullptr, (int64_t)t.dpack_elems);
-    if (t.overlap) HIPCHECK(hipEventRecord(t.ev_dpack, t.aux));
-  }
   // 2. forward, keeping Z (pre-activation) and Y (post) of every layer; with the fused tail the last four layers are one
   //    streaming launch that ends in the loss gradient (nothing of them is kept: tail_bwd32 recomputes what it needs)
   const int L = (int)t.layers.size();
@@ -833,7 +832,7 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
   const float* tp = t.d_pack + t.tail_pack_off;
   if (t.use_tail) {
     Tail32Params q;
-    q.in = t.Y[Lg - 1]; q.out = t.dbuf[t.ring]; q.n = n; q.H = t.tail.H; q.W = t.tail.W;
+    q.in = t.Y[Lg - 1]; q.out = t.d_dpred; q.n = n; q.H = t.tail.H; q.W = t.tail.W;
     q.w1f = tp + t.tail.t32_w1; q.b1 = tp + t.tail.t32_b1; q.w2f = tp + t.tail.t32_w2; q.b2 = tp + t.tail.t32_b2;
     q.w3f = tp + t.tail.t32_w3; q.b3 = tp + t.tail.t32_b3; q.wc = tp + t.tail.t32_wc;
     q.aff_out = nullptr; q.nan_guard = 0; q.nonfinite = nullptr; q.out_dtype = SRCFD_F32;
@@ -844,45 +843,35 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
   } else {
     int64_t oe = (int64_t)n * t.layers[L - 1].out_elems;
     nb = (int)std::min<int64_t>(1024, (oe + 255) / 256);
-    hipLaunchKernelGGL(mse_grad_f32, dim3(nb), dim3(256), 0, s, t.Y[L - 1], y, t.dbuf[0], oe, loss_scale, t.d_loss_partial);
+    hipLaunchKernelGGL(mse_grad_f32, dim3(nb), dim3(256), 0, s, t.Y[L - 1], y, t.dz[L - 1], oe, loss_scale, t.d_loss_partial);
   }
-  if (sse_dev) hipLaunchKernelGGL(sum_partials_f64, dim3(1), dim3(256), 0, s, t.d_loss_partial, nb, sse_dev);
-  // 4. backward.  Main stream: swish' -> data gradient -> swish' -> ... (the dependent chain); aux stream: the weight
-  //    gradients, each waiting only for its layer's dZ.  dZ buffers rotate through a ring of three, so the data-gradient
-  //    chain may run two layers ahead of the weight gradients before it has to wait for one of them.
-  int cur = 0;
-  constexpr int MAX_FINISH_GROUPS = 4;
-  int fblocks[MAX_FINISH_GROUPS] = {0, 0, 0, 0};       // workgroups of the merged slab-sum launches so far
-  FinishTable ftab[MAX_FINISH_GROUPS];
-  for (auto& ft : ftab) ft.nops = 0;
+  // 4. backward.  Main stream: [tail_bwd32 ->] swish' -> data gradient -> swish' -> ... (the dependent chain), then the weight
+  //    gradients of the layers below aux_from; second stream, forked ONCE (when dZ of layer aux_from exists): the weight
+  //    gradients of the layers from aux_from up, and the sum of the loss partials (nobody on the chain needs it).
+  FinishTable ftab;
+  ftab.nops = 0; ftab.overwrite = overwrite;
+  int fblocks = 0;                                     // workgroups of the merged slab-sum launch so far
   bool dz_done = false;  // the data-gradient GEMM below already multiplied by swish'(Z) of the layer it feeds (EpiAux mode 2)
-  hipStream_t ws = t.overlap ? t.aux : s;
-  if (t.overlap && t.dpack_elems) HIPCHECK(hipStreamWaitEvent(s, t.ev_dpack, 0));
-  if (t.use_tail) {      // every gradient of the last four layers + dZ of layer Lg - 1, from dpred (dbuf[1]) and that layer's Z / Y
+  const int aux_from = (t.overlap && t.aux_from < Lg) ? t.aux_from : Lg;   // Lg: everything on the caller's stream
+  bool sse_pending = sse_dev != nullptr;
+  if (t.use_tail) {      // every gradient of the last four layers + dZ of layer Lg - 1, from dpred and that layer's Z / Y
     TailBwdParams q;
-    q.y1 = t.Y[Lg - 1]; q.z1 = t.Z[Lg - 1]; q.dpred = t.dbuf[t.ring]; q.dz1 = t.dbuf[0]; q.slabs = t.d_tail_slabs;
+    q.y1 = t.Y[Lg - 1]; q.z1 = t.Z[Lg - 1]; q.dpred = t.d_dpred; q.dz1 = t.dz[Lg - 1]; q.slabs = t.d_tail_slabs;
     q.wf = tp + t.tail.wf; q.wb = tp + t.tail.wb; q.wt = tp + t.tail.wt; q.bias = tp + t.tail.bias;
     q.n = n; q.H = t.tail.H; q.W = t.tail.W;
     HIPCHECK(launch_tail_bwd32(q, t.num_cus, s));
     dz_done = true;
-    FinishOp& fo = ftab[0].op[ftab[0].nops++];
+    FinishOp& fo = ftab.op[ftab.nops++];
     fo.part = t.d_tail_slabs; fo.map = t.d_tail_gmap; fo.elems = TT_PARAMS; fo.nslices = tail_bwd32_blocks(n, q.H, q.W, t.num_cus);
     fo.K = 0x7fffffff; fo.N = 1; fo.Npad = 1; fo.CO = 1;   // one column, no bias row: every slot is a parameter of its own
     fo.groups = fo.nslices >= 256 ? 32 : (fo.nslices >= 64 ? 8 : (fo.nslices >= 8 ? 4 : 1));
-    fo.block0 = fblocks[0];
-    fblocks[0] += (TT_PARAMS + 256 / fo.groups - 1) / (256 / fo.groups);
+    fo.block0 = fblocks; fo.bias_skip = 0; fo.nextra = 0;
+    fblocks += (TT_PARAMS + 256 / fo.groups - 1) / (256 / fo.groups);
   }
-  for (int li = Lg - 1; li >= 0; --li) {
-    float* dZ = t.dbuf[cur];
-    int64_t e = (int64_t)n * t.layers[li].out_elems;
-    if (t.layers[li].swish && !dz_done) hipLaunchKernelGGL(swish_bwd_f32, grid(e), dim3(256), 0, s, t.Z[li], dZ, e);
-    dz_done = false;
-    if (t.overlap) {
-      HIPCHECK(hipEventRecord(t.ev_dz[li], s));
-      HIPCHECK(hipStreamWaitEvent(t.aux, t.ev_dz[li], 0));
-    }
+  // the weight gradients of layer li on stream st: one wgrad launch per op, the slab sums entered in the table
+  auto wgrad_layer = [&](const int li, hipStream_t st) -> int {
     const float* X = li == 0 ? x : t.Y[li - 1];
-    int in_layer = 0;
+    int first = -1;
     for (const TrainOp& op : t.ops) {
       if (op.layer != li) continue;
       GemmDesc d = op.fwd;
@@ -891,38 +880,53 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
       const int64_t elems = (int64_t)(d.K + 1) * d.Npad;
       if ((size_t)wp.nslices * elems > op.part_cap) { set_error("training: gradient slab buffer too small"); return SRCFD_EINVAL; }
       float* part = t.d_part + op.part_off;
-      launch_wgrad(d, wp, X, dZ, part, ws);
+      launch_wgrad(d, wp, X, t.dz[li], part, st);
       const int groups = wp.nslices >= 256 ? 32 : (wp.nslices >= 64 ? 8 : (wp.nslices >= 8 ? 4 : 1)), epb = 256 / groups;
-      // ops of one layer (the output phases of ConvT#0) add into the SAME bias parameters: the q-th op of every layer goes
-      // into merged launch q, and the launches of one stream run one after the other
-      if (in_layer >= MAX_FINISH_GROUPS || ftab[in_layer].nops >= MAX_FINISH_OPS) { set_error("training: more weight-gradient ops than the finish tables hold"); return SRCFD_EINVAL; }
-      FinishTable& ft = ftab[in_layer];
-      FinishOp& fo = ft.op[ft.nops++];
+      if (ftab.nops >= MAX_FINISH_OPS) { set_error("training: more weight-gradient ops than the finish table holds"); return SRCFD_EINVAL; }
+      const int me = ftab.nops++;
+      FinishOp& fo = ftab.op[me];
       fo.part = part; fo.map = op.d_gmap; fo.elems = elems; fo.nslices = wp.nslices; fo.K = d.K; fo.N = d.N; fo.Npad = d.Npad; fo.CO = d.CO;
-      fo.groups = groups; fo.block0 = fblocks[in_layer];
-      fblocks[in_layer] += (int)((elems + epb - 1) / epb);
-      ++in_layer;
+      fo.groups = groups; fo.block0 = fblocks; fo.bias_skip = 0; fo.nextra = 0;
+      fblocks += (int)((elems + epb - 1) / epb);
+      // ops of one layer (the output phases of ConvT#0) share the layer's bias: the first one sums the others' bias rows too
+      if (first < 0) first = me;
+      else {
+        FinishOp& f0 = ftab.op[first];
+        if (f0.nextra >= 3) { set_error("training: more than four ops in one layer"); return SRCFD_EINVAL; }
+        f0.extra[f0.nextra++] = me;
+        fo.bias_skip = 1;
+      }
     }
-    if (t.overlap) HIPCHECK(hipEventRecord(t.ev_wg[li], t.aux));
+    return SRCFD_OK;
+  };
+  for (int li = Lg - 1; li >= 0; --li) {
+    float* dZ = t.dz[li];
+    int64_t e = (int64_t)n * t.layers[li].out_elems;
+    if (t.layers[li].swish && !dz_done) hipLaunchKernelGGL(swish_bwd_f32, grid(e), dim3(256), 0, s, t.Z[li], dZ, e);
+    dz_done = false;
+    if (li == aux_from) {          // the one fork: dZ of the layers aux_from .. Lg - 1 exist
+      HIPCHECK(hipEventRecord(t.ev_fork, s));
+      HIPCHECK(hipStreamWaitEvent(t.aux, t.ev_fork, 0));
+      for (int lj = Lg - 1; lj >= aux_from; --lj) { const int rc = wgrad_layer(lj, t.aux); if (rc) return rc; }
+      if (sse_pending) { hipLaunchKernelGGL(sum_partials_f64, dim3(1), dim3(256), 0, t.aux, t.d_loss_partial, nb, sse_dev, overwrite); sse_pending = false; }
+    }
     if (li > 0) {
       const DgradOp& dg = t.dops[li - 1];
       GemmDesc d = dg.d;
       d.M = n * d.MH * d.MW;
-      const int nxt = (cur + 1) % t.ring;
-      // the ring slot about to be overwritten held dZ of layer li + ring - 1: its weight gradient must have read it
-      if (t.overlap && li + t.ring - 1 <= Lg - 1) HIPCHECK(hipStreamWaitEvent(s, t.ev_wg[li + t.ring - 1], 0));
       EpiAux aux;
       if (t.fuse_epilogues && t.layers[li - 1].swish && gemm_supports_epi_aux(d)) { aux.mode = 2; aux.zaux = t.Z[li - 1]; dz_done = true; }
-      HIPCHECK(launch_gemm_mfma(d, dZ, t.d_dpack + dg.w_off, t.d_zero_bias, t.dbuf[nxt], s, t.d_splitk, t.splitk_floats, false, aux));
-      cur = nxt;
+      HIPCHECK(launch_gemm_mfma(d, dZ, t.d_dpack + dg.w_off, t.d_zero_bias, t.dz[li - 1], s, t.d_splitk, t.splitk_floats, false, aux));
     }
   }
-  for (int q = 0; q < MAX_FINISH_GROUPS; ++q)   // all slabs are written (ws is in order): the merged launches sum them into grads
-    if (ftab[q].nops > 0) hipLaunchKernelGGL(wgrad_finish_all_f32, dim3((unsigned)fblocks[q]), dim3(256), 0, ws, ftab[q], grads);
-  if (t.overlap) {
+  for (int li = std::min(aux_from, Lg) - 1; li >= 0; --li) { const int rc = wgrad_layer(li, s); if (rc) return rc; }
+  if (sse_pending) hipLaunchKernelGGL(sum_partials_f64, dim3(1), dim3(256), 0, s, t.d_loss_partial, nb, sse_dev, overwrite);
+  if (aux_from < Lg) {
     HIPCHECK(hipEventRecord(t.ev_fin, t.aux));
     HIPCHECK(hipStreamWaitEvent(s, t.ev_fin, 0));  // aux is in order: this covers all of its kernels
   }
+  // all slabs are written: ONE launch sums them into grads
+  if (ftab.nops > 0) hipLaunchKernelGGL(wgrad_finish_all_f32, dim3((unsigned)fblocks), dim3(256), 0, s, ftab, grads);
   HIPCHECK(hipGetLastError());
   return SRCFD_OK;
 }
@@ -969,10 +973,18 @@ int srcfd_trainer_get_params(const srcfd_trainer* t, float* params_host) {
 int srcfd_trainer_forward_backward(srcfd_trainer* t, const float* params_dev, const float* x_dev, const float* y_dev, int n, float loss_scale,
                                    float* grads_dev, double* sse_dev, void* hip_stream) {
   return srcfd::abi_guard("srcfd_trainer_forward_backward", [&]() -> int {
+    return srcfd_trainer_forward_backward_ex(t, params_dev, x_dev, y_dev, n, loss_scale, grads_dev, sse_dev, 0, hip_stream);
+  });
+}
+
+int srcfd_trainer_forward_backward_ex(srcfd_trainer* t, const float* params_dev, const float* x_dev, const float* y_dev, int n, float loss_scale,
+                                      float* grads_dev, double* sse_dev, int flags, void* hip_stream) {
+  return srcfd::abi_guard("srcfd_trainer_forward_backward_ex", [&]() -> int {
     if (!t || !params_dev || !x_dev || !y_dev || !grads_dev) { set_error("bad arguments"); return SRCFD_EINVAL; }
+    if (flags & ~SRCFD_TRAIN_OVERWRITE) { set_error("srcfd_trainer_forward_backward_ex: unknown flag"); return SRCFD_EINVAL; }
     Trainer& tt = *reinterpret_cast<Trainer*>(t);
     hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
-    if (!tt.use_graph || n <= 0 || n > tt.max_batch) return srcfd::trainer_step(tt, params_dev, x_dev, y_dev, n, loss_scale, grads_dev, sse_dev, s);
+    if (!tt.use_graph || n <= 0 || n > tt.max_batch) return srcfd::trainer_step(tt, params_dev, x_dev, y_dev, n, loss_scale, grads_dev, sse_dev, flags, s);
     HIPCHECK(hipSetDevice(tt.device));
     const size_t xe = (size_t)n * tt.x_elems, ye = (size_t)n * tt.y_elems;
     if (((uintptr_t)x_dev | (uintptr_t)y_dev) % 16 == 0 && xe % 4 == 0 && ye % 4 == 0) {
@@ -985,14 +997,14 @@ int srcfd_trainer_forward_backward(srcfd_trainer* t, const float* params_dev, co
       HIPCHECK(hipMemcpyAsync(tt.d_ys, y_dev, ye * sizeof(float), hipMemcpyDeviceToDevice, s));
     }
     Trainer::StepKey key;
-    key.params = params_dev; key.grads = grads_dev; key.sse = sse_dev; key.n = n; key.loss_scale = loss_scale;
+    key.params = params_dev; key.grads = grads_dev; key.sse = sse_dev; key.n = n; key.flags = flags; key.loss_scale = loss_scale;
     Trainer::StepGraph* slot = nullptr;
     for (auto& g : tt.graphs) if (g.key == key) slot = &g;
     if (!slot && tt.graphs.size() < 8) { tt.graphs.emplace_back(); slot = &tt.graphs.back(); slot->key = key; }
     if (slot && slot->exec) { HIPCHECK(hipGraphLaunch(slot->exec, s)); return SRCFD_OK; }
     if (slot && ++slot->seen == 2) {  // every one-time set-up (function attributes, ...) happened on the first, plain pass
       HIPCHECK(hipStreamBeginCapture(tt.cap_stream, hipStreamCaptureModeThreadLocal));
-      int rc = srcfd::trainer_step(tt, params_dev, tt.d_xs, tt.d_ys, n, loss_scale, grads_dev, sse_dev, tt.cap_stream);
+      int rc = srcfd::trainer_step(tt, params_dev, tt.d_xs, tt.d_ys, n, loss_scale, grads_dev, sse_dev, flags, tt.cap_stream);
       hipGraph_t g = nullptr;
       hipError_t e = hipStreamEndCapture(tt.cap_stream, &g);
       if (rc == SRCFD_OK && e == hipSuccess && g) {
@@ -1004,7 +1016,7 @@ int srcfd_trainer_forward_backward(srcfd_trainer* t, const float* params_dev, co
       (void)hipGetLastError();  // capture not possible here: plain launches from now on for this key
       slot->seen = 3;
     }
-    return srcfd::trainer_step(tt, params_dev, tt.d_xs, tt.d_ys, n, loss_scale, grads_dev, sse_dev, s);
+    return srcfd::trainer_step(tt, params_dev, tt.d_xs, tt.d_ys, n, loss_scale, grads_dev, sse_dev, flags, s);
   });
 }
 

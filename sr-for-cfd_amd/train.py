@@ -94,16 +94,17 @@ class Trainer:
         except Exception:
             pass
 
-    def forward_backward(self, x, y, global_batch: Optional[int] = None) -> None:
-        """Accumulates this rank's gradient of the GLOBAL mean-squared error into self.grads."""
+    def forward_backward(self, x, y, global_batch: Optional[int] = None, overwrite: bool = False) -> None:
+        """Accumulates this rank's gradient of the GLOBAL mean-squared error into self.grads (and the squared-error sum into
+        self.sse); overwrite=True stores them instead (SRCFD_TRAIN_OVERWRITE: no zero-fill launches in front of the step)."""
         import torch
         n = int(x.shape[0])
         gb = global_batch if global_batch is not None else n
         st = torch.cuda.current_stream(self.device)
-        L.check(L.lib.srcfd_trainer_forward_backward(
+        L.check(L.lib.srcfd_trainer_forward_backward_ex(
             self._h, C.c_void_p(self.params.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), n,
             C.c_float(1.0 / (gb * self.out_elems)), C.c_void_p(self.grads.data_ptr()), C.c_void_p(self.sse.data_ptr()),
-            C.c_void_p(st.cuda_stream)))
+            L.TRAIN_OVERWRITE if overwrite else 0, C.c_void_p(st.cuda_stream)))
 
     def apply_adam(self) -> None:
         import torch
@@ -125,10 +126,11 @@ class Trainer:
         w = world_size()
         if global_batch is None:
             global_batch = n * w
-        self.grads.zero_()
-        self.sse.zero_()
         if n:
-            self.forward_backward(x, y, global_batch)
+            self.forward_backward(x, y, global_batch, overwrite=True)   # stores grads and sse: nothing to zero
+        else:                                                           # a rank without samples in a ragged last batch
+            self.grads.zero_()
+            self.sse.zero_()
         work = allreduce_sum_(self.grads, async_op=True)
         if work is not None:
             work.wait()          # stream-side wait (RCCL): Adam follows the reduction, the host runs on

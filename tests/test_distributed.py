@@ -165,7 +165,7 @@ def test_bench_eight_rank_rehearsal():
 def test_bench_refuses_mismatched_world_and_diagnostic_switches():
     rc, recs, err = _run_bench(["--gpus", "4"], {"SRCFD_BENCH_DRYRUN": "1", "WORLD_SIZE": "2", "RANK": "0"})
     assert rc != 0 and not recs and "WORLD_SIZE=2" in err
-    for var in ("SRCFD_TAIL_ABLATE", "SRCFD_MID_ABLATE", "SRCFD_TAIL_PROF"):
+    for var in ("SRCFD_TAIL_ABLATE", "SRCFD_MID_ABLATE", "SRCFD_TAIL_PROF", "SRCFD_TAIL32_ABLATE"):
         rc, recs, err = _run_bench([], {var: "1"})
         assert rc != 0 and not recs and var in err
     # A/B switches select another implementation than the shipped one: no headline under them either

@@ -172,6 +172,56 @@ def test_fused_tail_matches_layer_by_layer_step(srcfd, enc_weights, dec_weights,
 
 
 @pytest.mark.gpu
+def test_overwrite_mode_and_stream_split_do_not_change_a_bit(srcfd, enc_weights, dec_weights, monkeypatch):
+    """SRCFD_TRAIN_OVERWRITE (srcfd_trainer_forward_backward_ex): gradients and the squared-error sum are stored, not added --
+    over buffers full of garbage they must equal the accumulating call over zeroed buffers bit for bit (every parameter is
+    written by exactly one thread of the step's one slab-sum launch, shared ConvT biases included); calling the accumulating
+    form twice doubles.  Where the weight gradients are split between the two streams (SRCFD_TRAIN_AUX_FROM) and whether a
+    second stream is used at all changes nothing either."""
+    require_gpu(srcfd)
+    import torch
+    tr = importlib.import_module("sr-for-cfd_amd.train")
+    rng = np.random.default_rng(77)
+    n = 5
+    xd = torch.from_numpy(rng.standard_normal((n, 10, 10, 1)).astype(np.float32)).cuda()
+    yd = torch.from_numpy(rng.standard_normal((n, 400, 400, 1)).astype(np.float32)).cuda()
+
+    def run(aux_from, tail="1"):
+        if aux_from is None:
+            monkeypatch.delenv("SRCFD_TRAIN_AUX_FROM", raising=False)
+        else:
+            monkeypatch.setenv("SRCFD_TRAIN_AUX_FROM", aux_from)
+        monkeypatch.setenv("SRCFD_TRAIN_TAIL", tail)
+        t = tr.Trainer(srcfd.SRModel.from_weights(enc_weights, dec_weights, device=0), max_batch=8)
+        res = []
+        for rep in range(3):   # plain launches, capture, replay
+            t.grads.zero_(); t.sse.zero_()
+            t.forward_backward(xd, yd)
+            torch.cuda.synchronize()
+            acc = (float(t.sse.item()), t.grads.cpu().numpy().copy())
+            t.grads.fill_(float("nan")); t.sse.fill_(1e300)
+            t.forward_backward(xd, yd, overwrite=True)
+            torch.cuda.synchronize()
+            ow = (float(t.sse.item()), t.grads.cpu().numpy().copy())
+            assert ow[0] == acc[0] and np.array_equal(ow[1], acc[1]), rep
+            res.append(acc)
+        assert all(r[0] == res[0][0] and np.array_equal(r[1], res[0][1]) for r in res)
+        t.forward_backward(xd, yd)          # accumulates on top of the stored values
+        torch.cuda.synchronize()
+        assert float(t.sse.item()) == 2 * res[0][0] and np.array_equal(t.grads.cpu().numpy(), 2 * res[0][1])
+        return res[0]
+
+    base = run(None)
+    assert np.isfinite(base[1]).all() and np.abs(base[1]).max() > 0
+    for aux_from in ("0", "3", "6", "99"):
+        r = run(aux_from)
+        assert r[0] == base[0] and np.array_equal(r[1], base[1]), aux_from
+    lbl = run(None, tail="0")               # layer by layer: the four ConvT#0 phases AND the tail's layers go through the table
+    lbl2 = run("8", tail="0")
+    assert lbl2[0] == lbl[0] and np.array_equal(lbl2[1], lbl[1])
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("hw,n", [((6, 7), 3), ((3, 18), 2), ((9, 4), 5)])
 def test_fused_tail_on_other_image_sizes(srcfd, monkeypatch, hw, n):
     """tail32<TRAIN> / tail_bwd32 take the spatial size of the tail's input as a parameter: a small graph with the same last four

@@ -67,10 +67,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        t.grads.zero_()
-        t.forward_backward(x, y, gb)
-        tr.allreduce_sum_(t.grads)
-        t.apply_adam()
+        t.step(x, y, gb, return_loss=False)     # forward + backward (gradients stored, nothing zero-filled) + all-reduce + Adam
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
