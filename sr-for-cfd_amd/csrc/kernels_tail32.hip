@@ -79,13 +79,16 @@ __device__ __forceinline__ void lds_barrier32() {  // LDS traffic complete, glob
 // On this chip f32 MFMAs and vector instructions of the waves of a SIMD do NOT overlap (tools/microbench8.hip: their times
 // add), so every vector instruction dropped here is kernel time: the Newton-refined sigmoid of the layer-by-layer path
 // costs 7 instructions per activation, this 4 (3 with the packed add / multiply the compiler forms).
-__device__ __forceinline__ f32x4 swish_l2e(f32x4 u) {
-  f32x4 e, r;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(-u[i]);
-  e = e + 1.0f;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) r[i] = __builtin_amdgcn_rcpf(e[i]);
+// (`one2` = {1, 1} in a register pair the compiler cannot see through: with a literal 1.0f it forms four v_add_f32 instead of two
+// v_pk_add_f32 -- 28 of a round's ~670 vector instructions.)
+__device__ __forceinline__ f32x4 swish_l2e(f32x4 u, const f32x2& one2) {
+  f32x2 e0, e1;
+  e0[0] = __builtin_amdgcn_exp2f(-u[0]); e0[1] = __builtin_amdgcn_exp2f(-u[1]);
+  e1[0] = __builtin_amdgcn_exp2f(-u[2]); e1[1] = __builtin_amdgcn_exp2f(-u[3]);
+  e0 = e0 + one2; e1 = e1 + one2;
+  f32x4 r;
+  r[0] = __builtin_amdgcn_rcpf(e0[0]); r[1] = __builtin_amdgcn_rcpf(e0[1]);
+  r[2] = __builtin_amdgcn_rcpf(e1[0]); r[3] = __builtin_amdgcn_rcpf(e1[1]);
   return u * r;
 }
 
@@ -112,20 +115,18 @@ __device__ __forceinline__ f32x4 mfma16bf(const u32x4& a, const u32x4& b, const 
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(s16x8_t32, a), __builtin_bit_cast(s16x8_t32, b), c, 0, 0, 0);
 }
 __device__ __forceinline__ void split8_t32(const f32x4& v0, const f32x4& v1, u32x4& fh, u32x4& fm, u32x4& fl) {
-  uint32_t hm[8], mm[8], lm[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float x = i < 4 ? v0[i & 3] : v1[i & 3];
-    hm[i] = __builtin_bit_cast(uint32_t, x) & 0xffff0000u;
-    const float r1 = x - __builtin_bit_cast(float, hm[i]);
-    mm[i] = __builtin_bit_cast(uint32_t, r1) & 0xffff0000u;
-    lm[i] = __builtin_bit_cast(uint32_t, r1 - __builtin_bit_cast(float, mm[i]));
-  }
+  // two values at a time: the two exact subtractions are packed (v_pk_add_f32 with a negated source)
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    fh[q] = __builtin_amdgcn_perm(hm[2 * q + 1], hm[2 * q], 0x07060302u);
-    fm[q] = __builtin_amdgcn_perm(mm[2 * q + 1], mm[2 * q], 0x07060302u);
-    fl[q] = __builtin_amdgcn_perm(lm[2 * q + 1], lm[2 * q], 0x07060302u);
+    const f32x2 x = q < 2 ? f32x2{v0[2 * q], v0[2 * q + 1]} : f32x2{v1[2 * q - 4], v1[2 * q - 3]};
+    const u32x2 hb = __builtin_bit_cast(u32x2, x) & 0xffff0000u;
+    const f32x2 r1 = x - __builtin_bit_cast(f32x2, hb);
+    const u32x2 mb = __builtin_bit_cast(u32x2, r1) & 0xffff0000u;
+    const u32x2 lb = __builtin_bit_cast(u32x2, r1 - __builtin_bit_cast(f32x2, mb));
+    fh[q] = __builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u);
+    fm[q] = __builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u);
+    fl[q] = __builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u);
   }
 }
 
@@ -143,6 +144,8 @@ __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int H = p.H, W = p.W, SH = 2 * H, OW = 8 * W, OHs = 8 * H;
 
+  f32x2 one2 = {1.0f, 1.0f};
+  asm volatile("" : "+v"(one2));
   typedef T32Lay<X3> LY;
   for (int i = tid; i < LY::WC / 16; i += 512) reinterpret_cast<uint4*>(smem)[i] = make_uint4(0, 0, 0, 0);
   if (tid < 80) reinterpret_cast<float*>(smem + LY::WC)[tid] = tid < 73 ? p.wc[tid] : 0.f;
@@ -421,7 +424,7 @@ __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
     }
     // ---- the rest of the chain: second layer (both tap rows), third layer; the activation of one tile runs beside the
     // matrix work of the next (independent) one ----
-    if (!T32_ABL(1)) { a0 = swish_l2e(a0); a1 = swish_l2e(a1); }
+    if (!T32_ABL(1)) { a0 = swish_l2e(a0, one2); a1 = swish_l2e(a1, one2); }
     f32x4 b[2][2];
     if (X3) {
       // the second layer the same way: its B operand is the 8 activations a lane holds (k index 8 kg + j <-> channel 4 kg + j for
@@ -455,7 +458,7 @@ __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
     const int st_sel = (px_ok && p_on) ? 0 : 1;   // lanes / rounds with nothing to store write a dump granule instead (no branch)
 #pragma unroll
     for (int ty2 = 0; ty2 < 2; ++ty2) {
-      if (!T32_ABL(1)) { b[ty2][0] = swish_l2e(b[ty2][0]); b[ty2][1] = swish_l2e(b[ty2][1]); }
+      if (!T32_ABL(1)) { b[ty2][0] = swish_l2e(b[ty2][0], one2); b[ty2][1] = swish_l2e(b[ty2][1], one2); }
 #pragma unroll
       for (int tx2 = 0; tx2 < 2; ++tx2) {
         const f32x4 bs = b[ty2][tx2];
@@ -466,7 +469,7 @@ __global__ void __launch_bounds__(512) tail32(Tail32Params p) {
           c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wC[i * 64], bs[i], c0, 0, 0, 0);
           c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wC[(4 + i) * 64], bs[i], c1, 0, 0, 0);
         }
-        if (!T32_ABL(1)) { c0 = swish_l2e(c0); c1 = swish_l2e(c1); }
+        if (!T32_ABL(1)) { c0 = swish_l2e(c0, one2); c1 = swish_l2e(c1, one2); }
         const int o_a = st_sel ? LY::DUMP + lane * 16 : prow[2 * ty2] + p_off + 2 * tx2 * R_PLANE;
         const int o_b = st_sel ? LY::DUMP + lane * 16 : prow[2 * ty2 + 1] + p_off + 2 * tx2 * R_PLANE;
         if (T32_ABL(32)) { if (c0[0] + c1[1] == 123.456f) *reinterpret_cast<f32x4*>(smem + o_a) = c0; }
