@@ -24,6 +24,7 @@ Prints ONE JSON line (rank 0).  Besides the contract's keys it carries
                 fields/s, ms/step, its own roofline, rel-L2 vs the f64 oracle
   parity_path_x3  the same at SRCFD_PREC_FP32X3 (f32-grade: the two wide decoder
                 layers as six bf16 MFMAs on exactly split operands), same fields
+  fastest_path_within_1e-5  which of the two it was in this run (oracle-checked)
   train         BASELINE config 4: conv-AE training step, micro-batch 8 per
                 GPU, flat-gradient all-reduce (RCCL) + Adam, samples/s
   tiled         BASELINE config 5: 40x40x3 -> 1600x1600x3 through 4x4 tiles, f16
@@ -802,6 +803,16 @@ def main():
                 extra_errors["cpu_baseline"] = f"{type(e).__name__}: {e}"[:300]
     job.barrier()
 
+    # the fastest measured path whose first samples sit within north_star's 1e-5 of the float64 oracle (checked in THIS run)
+    best_1e5 = None
+    if job.rank == 0:
+        for rec_, key_ in ((parity, "fp32"), (parity_x3, "fp32x3")):
+            if rec_ is not None and rec_.get("rel_l2_vs_f64_oracle") is not None and rec_["rel_l2_vs_f64_oracle"] <= 1e-5 and \
+                    (best_1e5 is None or rec_["value"] > best_1e5["value"]):
+                best_1e5 = {"precision": key_, "value": rec_["value"], "unit": "fields/s", "ms_per_step": rec_["ms_per_step"],
+                            "rel_l2_vs_f64_oracle": rec_["rel_l2_vs_f64_oracle"], "tolerance": 1e-5,
+                            "record": "parity_path" if key_ == "fp32" else "parity_path_x3"}
+
     if job.rank == 0:
         out = {
             "metric": "SR fields/sec (10x10->400x400, 3-ch) @batch256", "value": head["value"], "unit": "fields/s",
@@ -818,7 +829,7 @@ def main():
             "launch_gap_ms": head.get("launch_gap_ms"),
             "roofline": head.get("roofline"), "last_plan": head.get("last_plan"),
             "cpu_baseline": cpu,
-            "parity_path": parity, "parity_path_x3": parity_x3, "train": train, "tiled": tiled, "host_io": host_io,
+            "parity_path": parity, "parity_path_x3": parity_x3, "fastest_path_within_1e-5": best_1e5, "train": train, "tiled": tiled, "host_io": host_io,
             "ms_per_step_rank_min_max": head.get("ms_per_step_rank_min_max"), "untimed_pre_warm_ms": head.get("untimed_pre_warm_ms"),
             "env": dict(env, gpu_state_before_headline=gpu_before, gpu_state_after_headline=gpu_after),
         }

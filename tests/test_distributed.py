@@ -213,6 +213,10 @@ def test_bench_two_ranks_share_one_gpu():
     # an N > 1 line is complete: CPU stand-in, both rooflines, the float64-oracle check of both paths, the host-buffer entry
     assert r["cpu_baseline"]["value"] > 0 and r["cpu_baseline"]["gpu_rel_l2_vs_f64_oracle"]["bf16"] < 2e-2
     assert r["parity_path"]["rel_l2_vs_f64_oracle"] <= 1e-5 and r["host_io"] is not None and "sub_record_errors" not in r, r.get("sub_record_errors")
+    assert r["parity_path_x3"]["rel_l2_vs_f64_oracle"] <= 1e-5
+    best = r["fastest_path_within_1e-5"]
+    assert best["precision"] in ("fp32", "fp32x3") and best["rel_l2_vs_f64_oracle"] <= 1e-5
+    assert best["value"] == max(r["parity_path"]["value"], r["parity_path_x3"]["value"])
     assert r["kernels_ms_sum"] * r["kernels_ms_in_step_scale"] <= r["ms_per_step"] * 1.0001
     assert r["nonfinite"] == 0 and r["roofline"]["frac"] > 0
     assert r["parity_path"]["roofline"]["avg_launch_ms"] <= r["parity_path"]["ms_per_step"] * 1.02
