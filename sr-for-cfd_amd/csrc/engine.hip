@@ -600,13 +600,22 @@ int Model::forward_generic(const float* x_dev, int n, const float* aff_in, const
         all = x3_off[q] >= 0 && gemm_x3_qualifies(dq);
       }
       if (all) {
-        for (size_t q = i; q < j; ++q) {
-          GemmDesc dq = ops[q].d;
-          dq.M = n * dq.MH * dq.MW;
-          const std::string nm = ops[q].name + "(x3)";
-          rc = launch(nm.c_str(), s, [&] { return launch_gemm_x3(dq, X, d_pack_x3 + x3_off[q], d_pack + ops[q].b_off, Y, s, num_cus); });
-          if (rc) return rc;
+        GemmDesc dsx[4];
+        const uint16_t* wx[4];
+        const float* bx[4];
+        const int cnt = (int)(j - i);
+        for (int q = 0; q < cnt; ++q) {
+          dsx[q] = ops[i + q].d;
+          dsx[q].M = n * dsx[q].MH * dsx[q].MW;
+          wx[q] = d_pack_x3 + x3_off[i + q];
+          bx[q] = d_pack + ops[i + q].b_off;
         }
+        // the layer's output phases: one launch (kernels_x3.hip, X3Group); a single-op layer: its own kernel
+        std::string nm = ops[i].name;
+        if (cnt > 1) { const size_t dot = nm.rfind(".ph"); if (dot != std::string::npos) nm.resize(dot); }
+        nm += "(x3)";
+        rc = launch(nm.c_str(), s, [&] { return launch_gemm_x3_group(dsx, cnt, X, wx, bx, Y, s, num_cus); });
+        if (rc) return rc;
         i = j - 1;
         continue;
       }

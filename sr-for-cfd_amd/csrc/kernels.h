@@ -141,6 +141,9 @@ bool gemm_x3_qualifies(const GemmDesc& d);
 int gemm_x3_kpad(const GemmDesc& d);
 void gemm_x3_split_weights(const GemmDesc& d, const float* B, uint16_t* out);
 hipError_t launch_gemm_x3(const GemmDesc& d, const float* X, const uint16_t* Wt, const float* bias, float* Y, hipStream_t s, int num_cus = 256);
+// the GEMMs of one layer (output phases of a strided transposed convolution), longest first: one launch where the kernel allows it
+hipError_t launch_gemm_x3_group(const GemmDesc* ds, int count, const float* X, const uint16_t* const* Wts, const float* const* biases, float* Y,
+                                hipStream_t s, int num_cus = 256);
 
 // Last layer + de-standardise + NaN guard + output cast in one kernel, for the layers gemm_fuses_finalize() accepts.
 bool gemm_fuses_finalize(const GemmDesc& d);

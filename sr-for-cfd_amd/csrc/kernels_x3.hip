@@ -116,13 +116,13 @@ __device__ __forceinline__ void x3_park_and_split(float* image, const int lane, 
 // (tools/microbench11.hip mode 3, profiles/r04/o_...: 2.5e-4 of the small plane's sum against 6e-7 in an accumulator of its own).
 // With all six products in one accumulator a layer came out at 3e-5 where the arithmetic is good to 1.5e-7.  So the hi x hi
 // products accumulate alone and the five small products in a set of their own (2^-8 terms last); the sets meet in one f32 add.
-__global__ void __launch_bounds__(256, 2) gemm_x3(GemmDesc d, const float* __restrict__ X, const uint16_t* __restrict__ Wt, int Kpad, int64_t wplane,
-                                                   const float* __restrict__ bias, float* __restrict__ Y) {
+__device__ __forceinline__ void gemm_x3_tile(const GemmDesc& d, const float* __restrict__ X, const uint16_t* __restrict__ Wt, const int Kpad, const int64_t wplane,
+                                             const float* __restrict__ bias, float* __restrict__ Y, const int bx, const int by) {
   extern __shared__ __attribute__((aligned(16))) char gsm[];
   uint16_t* Ws = reinterpret_cast<uint16_t*>(gsm);                 // [stage 2][plane 3][X3_BN][X3_PITCH]
   const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m0 = blockIdx.x * X3_BP, n0 = blockIdx.y * X3_BN;
+  const int m0 = bx * X3_BP, n0 = by * X3_BN;
 
   // lane l31 of either half decodes pixel l31 of the wave's tile; the lanes that load / store a row fetch its numbers by shuffle
   const int m = m0 + wave * 32 + l31;
@@ -224,6 +224,30 @@ __global__ void __launch_bounds__(256, 2) gemm_x3(GemmDesc d, const float* __res
     stage ^= 1;
   }
   x3_epilogue(d, accH, accR, bias, Y, image, n0, lane, orow);
+}
+
+__global__ void __launch_bounds__(256, 2) gemm_x3(GemmDesc d, const float* __restrict__ X, const uint16_t* __restrict__ Wt, int Kpad, int64_t wplane,
+                                                   const float* __restrict__ bias, float* __restrict__ Y) {
+  gemm_x3_tile(d, X, Wt, Kpad, wplane, bias, Y, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// The GEMMs of one layer (the four output phases of ConvT#0: K = 4, 2, 2, 1 taps x 256) as ONE launch, longest first: as four
+// launches each phase ends on a partly filled last round of workgroups (1014 / 936 / 936 / 864 workgroups on 512 slots) -- 13 % of
+// the layer's time by the workgroups' own durations.  The table travels as a kernel argument.
+struct X3Group {
+  GemmDesc d[4];
+  const uint16_t* Wt[4];
+  const float* bias[4];
+  int first[5];     // first linear workgroup id of op i; first[count] = total
+  int count;
+};
+__global__ void __launch_bounds__(256, 2) gemm_x3_group(const X3Group g, const float* __restrict__ X, float* __restrict__ Y) {
+  int op = 0;
+  while (op + 1 < g.count && (int)blockIdx.x >= g.first[op + 1]) ++op;     // block-uniform: scalar compares on the kernel arguments
+  const GemmDesc d = g.d[op];
+  const int lb = (int)blockIdx.x - g.first[op], nby = d.N / X3_BN;
+  const int Kpad = (d.K + X3_BK - 1) / X3_BK * X3_BK;
+  gemm_x3_tile(d, X, g.Wt[op], Kpad, (int64_t)d.N * Kpad, g.bias[op], Y, lb / nby, lb - (lb / nby) * nby);
 }
 
 // Short-K layers without taps (ConvT#1: K = 128, kernel == stride, 492 MB of f32 output per 768 samples): the k loop is four tiles
@@ -368,6 +392,33 @@ hipError_t launch_gemm_x3(const GemmDesc& d, const float* X, const uint16_t* Wt,
   if (e != hipSuccess) return e;
   dim3 grid((unsigned)((d.M + X3_BP - 1) / X3_BP), (unsigned)(d.N / X3_BN));
   hipLaunchKernelGGL(gemm_x3, grid, dim3(256), X3_LDS, s, d, X, Wt, Kpad, (int64_t)d.N * Kpad, bias, Y);
+  return hipGetLastError();
+}
+
+// ops of one layer: one launch when every op takes the tiled kernel (gemm_x3), else one launch per op
+hipError_t launch_gemm_x3_group(const GemmDesc* ds, int count, const float* X, const uint16_t* const* Wts, const float* const* biases, float* Y,
+                                hipStream_t s, int num_cus) {
+  bool group = count >= 2 && count <= 4;
+  for (int i = 0; group && i < count; ++i) group = ds[i].M > 0 && !gemm_x3_res_qualifies(ds[i]);
+  if (!group) {
+    for (int i = 0; i < count; ++i) {
+      hipError_t e = launch_gemm_x3(ds[i], X, Wts[i], biases[i], Y, s, num_cus);
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+  }
+  hipError_t e = lds_attr_once(reinterpret_cast<const void*>(gemm_x3_group), X3_LDS);
+  if (e != hipSuccess) return e;
+  X3Group g;
+  g.count = count;
+  int total = 0;
+  for (int i = 0; i < count; ++i) {
+    g.d[i] = ds[i]; g.Wt[i] = Wts[i]; g.bias[i] = biases[i];
+    g.first[i] = total;
+    total += ((ds[i].M + X3_BP - 1) / X3_BP) * (ds[i].N / X3_BN);
+  }
+  for (int i = count; i <= 4; ++i) g.first[i] = total;
+  hipLaunchKernelGGL(gemm_x3_group, dim3((unsigned)total), dim3(256), X3_LDS, s, g, X, Y);
   return hipGetLastError();
 }
 
