@@ -312,6 +312,8 @@ __global__ void __launch_bounds__(256) splitk_finish16(const float* __restrict__
 #define TAIL_ABL(bit) 0
 #endif
 
+// the 50x50x64 activation is read exactly once, the image written once: non-temporal on both sides (below)
+typedef unsigned u32x4nt __attribute__((ext_vector_type(4)));
 template <bool F16, int OUT, bool PROF = false, bool SEG = false>  // OUT: 0 f32, 1 bf16, 2 f16; PROF: per-wave section timers (diagnostic); SEG: samples cut into segments
 __global__ void __launch_bounds__(1024) tail16(TailParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -426,7 +428,7 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
     if (s0 >= 0) {
       const uint16_t* src = p.in + ((size_t)smp0 * 50 + s0) * 3200 + a_lane;   // wave-uniform row + the lane's constant offset
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) xb[kk] = *reinterpret_cast<const uint4*>(src + 16 * kk);
+      for (int kk = 0; kk < 4; ++kk) xb[kk] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4nt*>(src + 16 * kk)));
     }
   }
   float o_mean = 0.f, o_std = 1.f, o_mean_prev = 0.f, o_std_prev = 1.f;  // de-standardisation of D's sample / the one before
@@ -453,7 +455,7 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
           if (n_s >= 0) {
             const uint16_t* src = p.in + ((size_t)n_smp * 50 + n_s) * 3200 + a_lane;
   #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) xb[kk] = *reinterpret_cast<const uint4*>(src + 16 * kk);
+            for (int kk = 0; kk < 4; ++kk) xb[kk] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4nt*>(src + 16 * kk)));
           }
         } else {
         f32x16 acc = load_bias16(cst + TC_OFF_B2 + h * 64);
@@ -462,7 +464,7 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
         if (n_s >= 0) {
           const uint16_t* src = p.in + ((size_t)n_smp * 50 + n_s) * 3200 + a_lane;
   #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) xb[kk] = *reinterpret_cast<const uint4*>(src + 16 * kk);
+          for (int kk = 0; kk < 4; ++kk) xb[kk] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4nt*>(src + 16 * kk)));
         }
         uint32_t f2[8];
         swish_pack16<F16>(acc, f2, ab_sw);
@@ -608,9 +610,14 @@ __global__ void __launch_bounds__(1024) tail16(TailParams p) {
         }
         if (lane_on) {
           char* o = orow + d_olane;
-          if (OUT == 0) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-          else if (OUT == 1) *reinterpret_cast<uint2*>(o) = make_uint2(pack2<false>(v[0], v[1]), pack2<false>(v[2], v[3]));
-          else *reinterpret_cast<uint2*>(o) = make_uint2(pack2<true>(v[0], v[1]), pack2<true>(v[2], v[3]));
+          // the image is written once and never read back on the device: non-temporal stores keep it out of the way of what IS
+          // re-read (weights, the next launch's operands); with the non-temporal loads of the input: 1.6 % of the step, and mid16 in front
+          // of this kernel runs 2 % faster (profiles/r04/r_nontemporal_ab.txt)
+          typedef float f32x4nt __attribute__((ext_vector_type(4)));
+          typedef unsigned u32x2nt __attribute__((ext_vector_type(2)));
+          if (OUT == 0) __builtin_nontemporal_store(f32x4nt{v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4nt*>(o));
+          else if (OUT == 1) __builtin_nontemporal_store(u32x2nt{pack2<false>(v[0], v[1]), pack2<false>(v[2], v[3])}, reinterpret_cast<u32x2nt*>(o));
+          else __builtin_nontemporal_store(u32x2nt{pack2<true>(v[0], v[1]), pack2<true>(v[2], v[3])}, reinterpret_cast<u32x2nt*>(o));
         }
       };
       auto do_d = [&](const int item) {  // seam rows (sample / segment boundaries): called (not looped) so no conservative vmcnt(0) lands in front of it
