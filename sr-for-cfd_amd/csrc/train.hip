@@ -735,9 +735,7 @@ static int trainer_build(Trainer& t, const Model& model, int max_batch) {
   HIPCHECK(hipMalloc(&t.d_zero_bias, maxn * sizeof(float)));
   HIPCHECK(hipMemset(t.d_zero_bias, 0, maxn * sizeof(float)));
   // activations
-  size_t maxe = t.layers[0].in_elems;
   for (auto& L : t.layers) {
-    maxe = std::max(maxe, L.out_elems);
     float *z = nullptr, *y = nullptr;
     HIPCHECK(hipMalloc(&z, (size_t)max_batch * L.out_elems * sizeof(float)));
     if (L.swish) HIPCHECK(hipMalloc(&y, (size_t)max_batch * L.out_elems * sizeof(float)));
@@ -745,7 +743,6 @@ static int trainer_build(Trainer& t, const Model& model, int max_batch) {
     t.Z.push_back(z);
     t.Y.push_back(y);
   }
-  (void)maxe;
   {
     const int Lg = t.use_tail ? t.tail.first_layer : (int)t.layers.size();
     t.dz.assign(Lg, nullptr);
