@@ -527,9 +527,9 @@ class Job:
                 calls = per_rank // mb
 
                 def sstep(trn=trn, mb=mb, calls=calls):
-                    for c in range(calls):     # the first call of a step stores the gradients, the others add to them
+                    for c in range(calls):     # the first call of a step stores the gradients and re-packs the (new) parameters, the others add
                         lo = (c * mb) % 32
-                        trn.forward_backward(x32[lo:lo + mb], y32[lo:lo + mb], GB, overwrite=(c == 0))
+                        trn.forward_backward(x32[lo:lo + mb], y32[lo:lo + mb], GB, overwrite=(c == 0), same_params=(c > 0))
                     tr.allreduce_sum_(trn.grads)
                     trn.apply_adam()
 

@@ -322,6 +322,10 @@ int srcfd_trainer_forward_backward(srcfd_trainer* t, const float* params_dev, co
  * stored by exactly one thread of the step's last launch): a step needs no zero-fill launches in front of it.  Without the flag
  * this is srcfd_trainer_forward_backward (accumulation over several calls, e.g. micro-batches of one optimiser step). */
 #define SRCFD_TRAIN_OVERWRITE 1
+/* SRCFD_TRAIN_SAME_PARAMS: params_dev holds exactly what it held at this trainer's previous forward_backward call (the second and
+ * later micro-batches of one optimiser step): the per-call re-packing of the parameters into the kernels' operand layouts (one
+ * 18 us launch) is skipped.  Wrong gradients, silently, if the parameters did change -- the caller's contract. */
+#define SRCFD_TRAIN_SAME_PARAMS 2
 int srcfd_trainer_forward_backward_ex(srcfd_trainer* t, const float* params_dev, const float* x_dev, const float* y_dev, int n,
                                       float loss_scale, float* grads_dev, double* sse_dev, int flags, void* hip_stream);
 /* Keras Adam update, step counted from 1: alpha_t = lr*sqrt(1-beta2^t)/(1-beta1^t); p -= alpha_t*m/(sqrt(v)+eps). */

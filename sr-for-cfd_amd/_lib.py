@@ -16,6 +16,7 @@ OK, ENOENT, EIO, ENOMEM, ENODEV, EINVAL, EKEY, EHIP = 0, -2, -5, -12, -19, -22, 
 F32, F64, I32, I64, U8, STR, BF16, F16 = 0, 1, 2, 3, 4, 5, 16, 17
 PREC_FP32, PREC_BF16, PREC_FP32_NAIVE, PREC_F16, PREC_FP32X3 = 0, 1, 2, 3, 4
 TRAIN_OVERWRITE = 1   # srcfd_trainer_forward_backward_ex: grads and sse are written, not added into
+TRAIN_SAME_PARAMS = 2  # ... params unchanged since this trainer's previous call: the operand re-packing is skipped
 LAYER_CONV2D, LAYER_CONV2D_TRANSPOSE, LAYER_DENSE, LAYER_FLATTEN, LAYER_RESHAPE = 1, 2, 3, 4, 5
 ACT_LINEAR, ACT_SWISH, ACT_RELU, ACT_SIGMOID, ACT_TANH = 0, 1, 2, 3, 4
 FLAG_NAN_GUARD = 1

@@ -511,6 +511,7 @@ struct Trainer {
   // 4: 0.459 / 0.592 / 0.831, 5: 0.466 / - / 0.854, 6: 0.510 / - / 0.913; the per-layer forks of round 3: 0.503 / - / 0.90.
   hipStream_t aux = nullptr;
   int aux_from = -1;
+  bool packed_once = false;          // the operand packs were gathered at least once (SRCFD_TRAIN_SAME_PARAMS needs that)
   hipEvent_t ev_fork = nullptr;
   // (A third stream for the slab sums was tried: two forked streams that wait on each other send hipStreamEndCapture into an
   // endless recursion on ROCm 7.2, and with one-way dependencies the three-branch graph replayed level by level, 0.83 ms
@@ -794,8 +795,12 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
   auto grid = [](int64_t n_) { return dim3((unsigned)((n_ + 255) / 256)); };
   // 1. pack every operand of the step from the flat parameters: one launch (the data-gradient operands used to be packed on the
   //    second stream beside the forward pass -- a fork and a join of the replayed graph, ~10 us each, to hide a 12 us kernel)
-  hipLaunchKernelGGL(gather_pack_f32, grid(t.pack_elems / 4), dim3(256), 0, s, params, t.d_pack_map, t.d_pack, (int64_t)t.pack_elems,
-                     (const float*)t.d_pack_scale, (int64_t)(t.use_tail ? t.tail_pack_off : t.pack_elems));
+  //    SRCFD_TRAIN_SAME_PARAMS: the caller vouches that params_dev holds what it held at this trainer's previous call (the second
+  //    and later micro-batches of one optimiser step): the packs are still right, the launch is skipped.
+  if (!((flags & SRCFD_TRAIN_SAME_PARAMS) && t.packed_once))
+    hipLaunchKernelGGL(gather_pack_f32, grid(t.pack_elems / 4), dim3(256), 0, s, params, t.d_pack_map, t.d_pack, (int64_t)t.pack_elems,
+                       (const float*)t.d_pack_scale, (int64_t)(t.use_tail ? t.tail_pack_off : t.pack_elems));
+  t.packed_once = true;
   // 2. forward, keeping Z (pre-activation) and Y (post) of every layer; with the fused tail the last four layers are one
   //    streaming launch that ends in the loss gradient (nothing of them is kept: tail_bwd32 recomputes what it needs)
   const int L = (int)t.layers.size();
@@ -981,7 +986,7 @@ int srcfd_trainer_forward_backward_ex(srcfd_trainer* t, const float* params_dev,
                                       float* grads_dev, double* sse_dev, int flags, void* hip_stream) {
   return srcfd::abi_guard("srcfd_trainer_forward_backward_ex", [&]() -> int {
     if (!t || !params_dev || !x_dev || !y_dev || !grads_dev) { set_error("bad arguments"); return SRCFD_EINVAL; }
-    if (flags & ~SRCFD_TRAIN_OVERWRITE) { set_error("srcfd_trainer_forward_backward_ex: unknown flag"); return SRCFD_EINVAL; }
+    if (flags & ~(SRCFD_TRAIN_OVERWRITE | SRCFD_TRAIN_SAME_PARAMS)) { set_error("srcfd_trainer_forward_backward_ex: unknown flag"); return SRCFD_EINVAL; }
     Trainer& tt = *reinterpret_cast<Trainer*>(t);
     hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
     if (!tt.use_graph || n <= 0 || n > tt.max_batch) return srcfd::trainer_step(tt, params_dev, x_dev, y_dev, n, loss_scale, grads_dev, sse_dev, flags, s);

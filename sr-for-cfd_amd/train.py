@@ -94,9 +94,11 @@ class Trainer:
         except Exception:
             pass
 
-    def forward_backward(self, x, y, global_batch: Optional[int] = None, overwrite: bool = False) -> None:
+    def forward_backward(self, x, y, global_batch: Optional[int] = None, overwrite: bool = False, same_params: bool = False) -> None:
         """Accumulates this rank's gradient of the GLOBAL mean-squared error into self.grads (and the squared-error sum into
-        self.sse); overwrite=True stores them instead (SRCFD_TRAIN_OVERWRITE: no zero-fill launches in front of the step)."""
+        self.sse); overwrite=True stores them instead (SRCFD_TRAIN_OVERWRITE: no zero-fill launches in front of the step).
+        same_params=True: self.params has not changed since this trainer's previous call (later micro-batches of one
+        optimiser step) -- the re-packing of the parameters is skipped (SRCFD_TRAIN_SAME_PARAMS)."""
         import torch
         n = int(x.shape[0])
         gb = global_batch if global_batch is not None else n
@@ -104,7 +106,7 @@ class Trainer:
         L.check(L.lib.srcfd_trainer_forward_backward_ex(
             self._h, C.c_void_p(self.params.data_ptr()), C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), n,
             C.c_float(1.0 / (gb * self.out_elems)), C.c_void_p(self.grads.data_ptr()), C.c_void_p(self.sse.data_ptr()),
-            L.TRAIN_OVERWRITE if overwrite else 0, C.c_void_p(st.cuda_stream)))
+            (L.TRAIN_OVERWRITE if overwrite else 0) | (L.TRAIN_SAME_PARAMS if same_params else 0), C.c_void_p(st.cuda_stream)))
 
     def apply_adam(self) -> None:
         import torch

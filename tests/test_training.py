@@ -209,6 +209,17 @@ def test_overwrite_mode_and_stream_split_do_not_change_a_bit(srcfd, enc_weights,
         t.forward_backward(xd, yd)          # accumulates on top of the stored values
         torch.cuda.synchronize()
         assert float(t.sse.item()) == 2 * res[0][0] and np.array_equal(t.grads.cpu().numpy(), 2 * res[0][1])
+        for rep in range(3):                # SRCFD_TRAIN_SAME_PARAMS: the re-packing is skipped, nothing else changes (plain, capture, replay)
+            t.forward_backward(xd, yd, overwrite=True, same_params=True)
+            torch.cuda.synchronize()
+            assert float(t.sse.item()) == res[0][0] and np.array_equal(t.grads.cpu().numpy(), res[0][1]), rep
+        t.params.mul_(1.5)                  # ... and a caller that breaks the contract gets the OLD parameters' gradients
+        t.forward_backward(xd, yd, overwrite=True, same_params=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(t.grads.cpu().numpy(), res[0][1])
+        t.forward_backward(xd, yd, overwrite=True)
+        torch.cuda.synchronize()
+        assert not np.array_equal(t.grads.cpu().numpy(), res[0][1])
         return res[0]
 
     base = run(None)
