@@ -26,6 +26,7 @@
 
 #include "act_device.h"
 #include "engine.h"
+#include "train_enc.h"
 #include "train_tail.h"
 
 namespace srcfd {
@@ -538,6 +539,9 @@ struct Trainer {
   // The last four layers as two launches (train_tail.h): tail32<TRAIN> forward, tail_bwd32 backward.  SRCFD_TRAIN_TAIL=0: layer by layer.
   TrainTailPlan tail;
   bool use_tail = false;
+  // encoder_10's four layers forward as two launches (train_enc.hip) instead of six.  SRCFD_TRAIN_ENC=0: layer by layer.
+  bool use_enc = false;
+  float* d_enc_partial = nullptr;    // [50][max_batch][128]
   int num_cus = 256;
   size_t tail_pack_off = 0;          // the tail's operands sit behind the forward pack in d_pack
   float* d_pack_scale = nullptr;     // factors of those slots
@@ -556,7 +560,7 @@ Trainer::~Trainer() {
   if (d_xs) (void)hipFree(d_xs);
   if (d_ys) (void)hipFree(d_ys);
   for (float* b : dz) if (b) (void)hipFree(b);
-  for (void* p : {(void*)d_pack, (void*)d_pack_map, (void*)d_dpred, (void*)d_zero_bias, (void*)d_part, (void*)d_loss_partial, (void*)d_splitk, (void*)d_pack_scale, (void*)d_tail_slabs,
+  for (void* p : {(void*)d_pack, (void*)d_pack_map, (void*)d_dpred, (void*)d_enc_partial, (void*)d_zero_bias, (void*)d_part, (void*)d_loss_partial, (void*)d_splitk, (void*)d_pack_scale, (void*)d_tail_slabs,
                   (void*)d_tail_gmap})
     if (p) (void)hipFree(p);
   for (size_t i = 0; i < Z.size(); ++i) {
@@ -715,6 +719,14 @@ static int trainer_build(Trainer& t, const Model& model, int max_batch) {
   }
   t.part_elems = part_need;
   HIPCHECK(hipMalloc(&t.d_part, t.part_elems * sizeof(float)));
+  {
+    const char* e = getenv("SRCFD_TRAIN_ENC");
+    bool ok = !(e && atoi(e) == 0) && t.ops.size() >= 5 && t.layers.size() >= 4;
+    for (int i = 0; ok && i < 4; ++i) ok = t.ops[i].layer == i;                 // one op per layer, the first four layers
+    ok = ok && t.ops[4].layer != 3 && train_enc_qualifies(t.ops[0].fwd, t.ops[1].fwd, t.ops[2].fwd, t.ops[3].fwd);
+    t.use_enc = ok;
+    if (ok) HIPCHECK(hipMalloc(&t.d_enc_partial, (size_t)50 * max_batch * 128 * sizeof(float)));
+  }
   // dgrad plan
   std::vector<float> dpack;
   build_dgrad(im, t.layers, t.dops, dpack);
@@ -805,7 +817,22 @@ static int trainer_step(Trainer& t, const float* params, const float* x, const f
   //    streaming launch that ends in the loss gradient (nothing of them is kept: tail_bwd32 recomputes what it needs)
   const int L = (int)t.layers.size();
   const int Lg = t.use_tail ? t.tail.first_layer : L;   // layers [0, Lg) run layer by layer
-  for (size_t i = 0; i < t.ops.size();) {
+  size_t i0 = 0;
+  if (t.use_enc && Lg >= 4) {
+    TrainEncParams q;
+    q.x = x; q.n = n;
+    q.w0 = t.d_pack + t.ops[0].w_off; q.b0 = t.d_pack + t.ops[0].b_off;
+    q.w1 = t.d_pack + t.ops[1].w_off; q.b1 = t.d_pack + t.ops[1].b_off;
+    q.wd = t.d_pack + t.ops[2].w_off; q.bd = t.d_pack + t.ops[2].b_off;
+    q.wl = t.d_pack + t.ops[3].w_off; q.bl = t.d_pack + t.ops[3].b_off;
+    q.nl = t.ops[3].fwd.N; q.nl_pad = t.ops[3].fwd.Npad;
+    for (int li = 0; li < 4; ++li) q.swish[li] = t.layers[li].swish ? 1 : 0;
+    q.z0 = t.Z[0]; q.y0 = t.Y[0]; q.z1 = t.Z[1]; q.y1 = t.Y[1]; q.z2 = t.Z[2]; q.y2 = t.Y[2]; q.z3 = t.Z[3]; q.y3 = t.Y[3];
+    q.partial = t.d_enc_partial;
+    HIPCHECK(launch_train_enc(q, s));
+    i0 = 4;
+  }
+  for (size_t i = i0; i < t.ops.size();) {
     const TrainOp& op = t.ops[i];
     if (op.layer >= Lg) break;
     GemmDesc ds[4];

@@ -127,12 +127,16 @@ def test_gradients_match_autograd_oracle(srcfd, oracle, enc_weights, dec_weights
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [1, 3, 8])
-def test_fused_tail_matches_layer_by_layer_step(srcfd, enc_weights, dec_weights, monkeypatch, n):
-    """The last four layers as two launches (tail32<TRAIN> forward, tail_bwd32 backward with recomputation;
-    csrc/train_tail.hip) against the layer-by-layer step (SRCFD_TRAIN_TAIL=0): same loss, same gradient per tensor
-    up to f32 summation order.  n = 1 and 3 leave the last 16-pixel tile partial (2500 n is not a multiple of 16);
-    targets with structure near the image border exercise the output conv's SAME padding in the gradient."""
+@pytest.mark.parametrize("switch,n", [("SRCFD_TRAIN_TAIL", 1), ("SRCFD_TRAIN_TAIL", 3), ("SRCFD_TRAIN_TAIL", 8),
+                                      ("SRCFD_TRAIN_ENC", 1), ("SRCFD_TRAIN_ENC", 7), ("SRCFD_TRAIN_ENC", 19)])
+def test_fused_stages_match_layer_by_layer_step(srcfd, enc_weights, dec_weights, monkeypatch, switch, n):
+    """SRCFD_TRAIN_TAIL: the last four layers as two launches (tail32<TRAIN> forward, tail_bwd32 backward with recomputation;
+    csrc/train_tail.hip) against the layer-by-layer step (= 0): same loss, same gradient per tensor up to f32 summation
+    order.  n = 1 and 3 leave the last 16-pixel tile partial (2500 n is not a multiple of 16); targets with structure near
+    the image border exercise the output conv's SAME padding in the gradient.
+    SRCFD_TRAIN_ENC: the encoder's four layers forward as two launches (csrc/train_enc.hip: the dense layer's K dimension cut
+    over 50 workgroups, every layer's pre-activation and activation stored) against the six generic launches; n = 1, 7 leave
+    the 16-sample group partial, n = 19 spans two groups."""
     require_gpu(srcfd)
     import torch
     from oracle import sr_oracle_autograd as ag
@@ -145,8 +149,8 @@ def test_fused_tail_matches_layer_by_layer_step(srcfd, enc_weights, dec_weights,
     xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
 
     def run(env):
-        monkeypatch.setenv("SRCFD_TRAIN_TAIL", env)
-        t = tr.Trainer(srcfd.SRModel.from_weights(enc_weights, dec_weights, device=0), max_batch=8)
+        monkeypatch.setenv(switch, env)
+        t = tr.Trainer(srcfd.SRModel.from_weights(enc_weights, dec_weights, device=0), max_batch=max(8, n))
         out = []
         for _ in range(3):   # the third call replays the captured graph
             t.grads.zero_()
@@ -161,6 +165,7 @@ def test_fused_tail_matches_layer_by_layer_step(srcfd, enc_weights, dec_weights,
     sse0, g0 = run("0")
     sse1, g1 = run("1")
     assert abs(sse1 - sse0) <= 2e-6 * abs(sse0)
+    assert not np.array_equal(g0, g1)      # the switch did select other kernels
     off = 0
     both = {**enc_weights, **dec_weights}
     for name in ag.flat_order(enc_weights, dec_weights):
