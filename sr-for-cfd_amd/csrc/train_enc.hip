@@ -38,8 +38,9 @@ __global__ void __launch_bounds__(256) train_enc_a(TrainEncParams q) {
   // The matrix stages' A operands (this wave's 16 channels of conv2d_1: one float per k-step and lane; its two feature tiles of the
   // dense slice) depend on nothing computed here: all 176 loads are issued first and land while conv2d runs -- read at their point
   // of use they were 144 + 32 dependent round trips to L2 (29 us for this launch instead of 17).  The small operands of the vector
-  // stage and the biases likewise.  (What is left is 176 four-byte loads per lane from the engine's B[K][Npad] operand layout; a pack
-  // in MFMA-fragment order -- 16-byte loads, as enc32 has -- would be the next step.)
+  // stage and the biases likewise.  (A pack in MFMA-fragment order -- 36 + 8 sixteen-byte loads per lane instead of 176 four-byte
+  // ones -- was measured: 17.4 -> 16.6 us here, + 2.8 us in the step's operand gather for the 0.5 M extra slots.  Not kept: what is
+  // left of the launch is a sum of small latencies, not load instructions.)
   const int c0 = 64 * hf + 16 * wave;
   float wa[144], wdn[2][16], w9[9];
   const int ci = tid >> 2, sq = 4 * (tid & 3);                     // conv2d: thread = (channel ci, four samples)
