@@ -59,7 +59,7 @@ AB_ENV_OFF_WHEN_ZERO = ("SRCFD_ENC", "SRCFD_DENSE1")
 AB_ENV_DEFAULT_VALUE = {"SRCFD_MID": "3"}    # workgroup shape of mid16: 3 = 4 waves x 64 pixels (shipped), 2 = 8 x 64, 1 = 8 x 32; 0 = generic GEMMs
 AB_ENV_ON_WHEN_SET = ("SRCFD_NO_ENC32", "SRCFD_NO_DENSE_SKINNY", "SRCFD_NO_TAIL32", "SRCFD_NO_GEMM32_BIG", "SRCFD_NO_PAIR", "SRCFD_NO_TRIPLE")
 AB_ENV_ANY_VALUE = ("SRCFD_TAIL", "SRCFD_TAIL_SEG", "SRCFD_MID_WAVES", "SRCFD_MID_ORDER", "SRCFD_GRAPH", "SRCFD_LIB", "SRCFD_TRAIN_OVERLAP", "SRCFD_TRAIN_GRAPH",
-                    "SRCFD_TRAIN_FUSE", "SRCFD_TRAIN_TAIL", "SRCFD_TRAIN_AUX_FROM")
+                    "SRCFD_TRAIN_FUSE", "SRCFD_TRAIN_TAIL", "SRCFD_TRAIN_ENC", "SRCFD_TRAIN_AUX_FROM")
 # kernel sources whose content the committed PMC traffic files are stamped with (tools/pmc_traffic.py): a traffic figure taken
 # on other kernels than the ones in this tree is not reported
 TRAFFIC_SOURCES = {"pmc_traffic_tail.json": ("kernels_bf16.hip", "tail16_layout.h", "dev16.h", "kernels16.h"),
